@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — image pairs/s of the two-view relative-pose hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic two-view pairs, 8192 SIFT-style float32
+descriptors (dim 128) per view, 4096 RANSAC essential-matrix hypotheses per pair.  One step =
+one pass of the hot path over a batch of --pairs such pairs per GPU, inputs resident in HBM:
+
+    row norms -> L2 top-2 (fp32 MFMA) -> ratio test -> compaction -> Sampson scoring of H
+    hypotheses -> best -> inlier mask -> [host: 3x3 SVD decomposition] -> 4-candidate
+    triangulation + cheirality vote -> pose table  (-> all_gather of the table when N > 1)
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU; prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pose_estimation_amd import matching, pipeline, synthetic  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+N_FEAT, DIM, N_HYP = 8192, 128, 4096
+THR_PX = 1.0
+
+
+def make_hypotheses(rng, R, t, H):
+    """H essential-matrix hypotheses for one pair: a few near the truth, the rest perturbed."""
+    E = np.empty((H, 9), np.float32)
+    for h in range(H):
+        s = 0.0 if h == H // 3 else (0.002 if h % 16 == 0 else 0.05)
+        w = rng.normal(0, s, 3)
+        E[h] = synthetic.essential_from_pose((np.eye(3) + synthetic.skew(w)) @ R, t + rng.normal(0, 2 * s, 3)).reshape(9)
+    return E
+
+
+def make_batch(pairs, rank, dev):
+    d1, d2, k1, k2, E, truth = [], [], [], [], [], []
+    for p in range(pairs):
+        sc = synthetic.two_view_pair(n=N_FEAT, dim=DIM, seed=1002 + 7919 * rank + p)
+        d1.append(sc["desc1"]); d2.append(sc["desc2"]); k1.append(sc["kp1"]); k2.append(sc["kp2"])
+        E.append(make_hypotheses(np.random.default_rng(p + 31 * rank), sc["R"], sc["t"], N_HYP))
+        truth.append((sc["R"], sc["t"]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev)
+    return dict(desc_q=t(d1), desc_t=t(d2), kp_q=t(k1), kp_t=t(k2), E=t(E), truth=truth,
+                host=dict(desc_q=d1, desc_t=d2, kp_q=k1, kp_t=k2, E=E))
+
+
+def cpu_baseline(batch, n_pairs, threads):
+    """The CPU oracle ('port') over the same stages on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    orc.set_num_threads(threads)
+    thr_sq = np.float32((THR_PX / synthetic.FX) ** 2)
+    h = batch["host"]
+    t0 = time.perf_counter()
+    for p in range(n_pairs):
+        idx, a, b = orc.match_l2_top2(h["desc_q"][p], h["desc_t"][p])
+        keep = orc.ratio_filter_l2(idx, a, b, 0.75)
+        m = orc.compact_matches(idx, keep, h["kp_q"][p], h["kp_t"][p])
+        n = m["n_match"]
+        pts = [m[k][:n] for k in ("x1", "y1", "x2", "y2")]
+        cnt = orc.score_essential(h["E"][p], *pts, thr_sq)
+        bi, _ = orc.select_best(cnt)
+        mask = orc.inlier_mask_essential(h["E"][p][bi], *pts, thr_sq, N_FEAT)
+        from pose_estimation_amd import geometry
+        P1, P2, _, _ = geometry.candidate_projections(h["E"][p][bi].reshape(1, 3, 3))
+        for c in range(4):
+            orc.triangulate(P1[0, c], P2[0, c], *pts, mask)
+    dt = time.perf_counter() - t0
+    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n_pairs} pair(s) of the same workload through oracle/posehot_oracle.c (OpenMP, {threads} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=16, help="pairs per step per GPU")
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="verify pose accuracy of the last step against ground truth")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P = args.pairs
+    batch = make_batch(P, rank, dev)
+    thr_sq = float(np.float32((THR_PX / synthetic.FX) ** 2))
+    gathered = torch.empty((world * P, 16), dtype=torch.float32, device=dev) if world > 1 else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    state = {"step": -1}
+
+    def match():
+        nq = matching.row_sqnorm(batch["desc_q"])
+        nt = matching.row_sqnorm(batch["desc_t"])
+        k = state["step"]
+        if k >= 0:
+            ev[k][0].record()
+        r = matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq, norm_t=nt)
+        if k >= 0:
+            ev[k][1].record()
+        return (*r, "l2")
+
+    def step():
+        out = pipeline.relative_pose_batch(match, batch["kp_q"], batch["kp_t"], None, None, batch["E"], thr_sq)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out["table"])
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        state["step"] = k
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    state["step"] = -1
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    flops = 2.0 * N_FEAT * N_FEAT * DIM * P
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+
+    if args.check and rank == 0:
+        from pose_estimation_amd import geometry
+        tab = out["table"].cpu().numpy()
+        for p, (R, t) in enumerate(batch["truth"]):
+            ra = geometry.rotation_angle_deg(tab[p, :9].reshape(3, 3), R)
+            ta = geometry.direction_angle_deg(tab[p, 9:12], t)
+            print(f"# pair {p}: matches {int(tab[p,13])} inliers {int(tab[p,12])} rot err {ra:.4f} deg, t dir err {ta:.4f} deg",
+                  file=sys.stderr)
+
+    if rank == 0:
+        res = {
+            "metric": "image pairs/sec (relative pose, whole node) at 8k feats",
+            "value": world * P * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
+                                   "4096 essential-matrix hypotheses per pair", "pairs_per_step_per_gpu": P,
+                       "features": N_FEAT, "dim": DIM, "hypotheses": N_HYP, "ratio": 0.75, "threshold_px": THR_PX,
+                       "hypothesis_source": "resident in HBM (pre-generated around ground truth; minimal solver not in the timed region)",
+                       "parallelism": f"pairs sharded over {world} rank(s), final all_gather of the [pairs,16] pose table"},
+            "hyps_per_sec": world * P * N_HYP * args.steps / dt,
+            "roofline": {"kernel": "l2_top2_f32_kernel<128>", "bound": "mfma", "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": None, "launch_ms": kern_ms,
+                         "algorithmic_flops_per_launch": flops},
+        }
+        if world == 1 and args.cpu_pairs > 0:
+            threads = min(16, os.cpu_count() or 1)
+            res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+/*
+ * posehot.h — C ABI of libposehot.so, the MI355X (gfx950) camera-pose hot path.
+ *
+ * Boundary: the reference (alirezafalah/pose_estimation) has no FFI; its only
+ * seam is the set of module-level Python functions called from the per-image loops
+ * (main.py:187,196; validate_pose.py:360,369).  Each entry point below cites the reference
+ * lines it replaces or, for the three north-star subsystems that have no reference code
+ * (matching, RANSAC scoring, triangulation), the SURVEY.md §8 row that specifies it.
+ *
+ * Conventions (all entry points):
+ *  - every data pointer is a DEVICE pointer owned by the caller (torch tensors); the library
+ *    allocates nothing; scratch comes in through (ws, ws_bytes), sized by the *_ws_bytes query;
+ *  - launches are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default);
+ *  - return value: PH_OK (0) or a negative PH_ERR_* code; never throws, never aborts — the
+ *    reference's "sentinel return, caller skips the item" convention (main.py:91-107);
+ *  - batched: B independent items (image pairs / frames) per call; per-item valid counts
+ *    (`n_valid`-style arrays, device int32) allow ragged items inside a fixed row stride;
+ *  - re-entrant; no global state.
+ *
+ * The float arithmetic of every decision (which hypothesis wins, which point is an inlier,
+ * which neighbour is best) is a fixed sequence of IEEE-754 binary32 fma/mul operations that is
+ * written out in DESIGN.md §"Arithmetic contracts"; the CPU oracle (oracle/) restates the same
+ * sequence, which is what makes inlier masks and match indices bit-exact across CPU and GPU.
+ */
+#ifndef POSEHOT_H
+#define POSEHOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PH_VERSION 100 /* 0.1.0 */
+
+#define PH_OK 0
+#define PH_ERR_INVALID_ARG (-1) /* null pointer, negative size, misaligned pointer              */
+#define PH_ERR_UNSUPPORTED (-2) /* a size/dtype this build has no kernel for                    */
+#define PH_ERR_WORKSPACE (-3)   /* ws_bytes smaller than the matching *_ws_bytes() answer       */
+#define PH_ERR_LAUNCH (-4)      /* hipLaunch / hipMemsetAsync reported an error                 */
+
+/* Sentinels written for "no such neighbour" (empty / single-row train sets). */
+#define PH_NO_INDEX (-1)
+#define PH_HAMMING_NONE 0x7fffffff
+
+int ph_version(void);
+const char* ph_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * (1) Brute-force descriptor matching + Lowe ratio test.            SURVEY.md §8 row a-9
+ *     No reference code (main.py has no matcher); semantics are this library's contract:
+ *     nearest and second-nearest train row per query row, ties -> lowest train index.
+ *
+ * Descriptor tables are [V][n_rows][bytes] (binary) or [V][n_rows][dim] (float); a pair b
+ * matches view view_q[b] (queries) against view view_t[b] (train).  view_q/view_t may be NULL,
+ * meaning view b of each table.  n_q/n_t (device int32 [B], may be NULL) give the number of
+ * valid rows of the pair's query/train view (<= nq/nt, the row strides of the tables).
+ * Outputs are [B][nq]; rows >= n_q[b] get idx = PH_NO_INDEX.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Hamming, 256-bit (bytes == 32) descriptors.  d1/d2 = best / second-best distance. */
+size_t ph_match_hamming_ws_bytes(int B, int nq, int nt);
+int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_t,
+                          const int32_t* view_q, const int32_t* view_t,
+                          const int32_t* n_q, const int32_t* n_t,
+                          int B, int nq, int nt, int bytes,
+                          int32_t* idx, int32_t* d1, int32_t* d2,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* Squared row norms |a_r|^2 of a [n_rows][dim] f32 table (natural-order fma chain from 0),
+ * computed ONCE per view table and reused by every pair that touches the view. */
+int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float* out, void* stream);
+
+/* Squared-L2 on float descriptors (dim == 128 or 64), fp32 MFMA contraction with a fused
+ * top-2 reduction.  norm_q / norm_t are the ph_row_sqnorm outputs of the two tables
+ * ([Vq][nq], [Vt][nt]).  precision: 0 = exact f32 (v_mfma_f32_32x32x2_f32); 1 = bf16
+ * operands (not built yet: PH_ERR_UNSUPPORTED).
+ * d1sq/d2sq = squared distances of the best / second-best train row (+inf when absent). */
+#define PH_PRECISION_F32 0
+#define PH_PRECISION_BF16 1
+size_t ph_match_l2_ws_bytes(int B, int nq, int nt, int dim);
+int ph_match_l2_top2(const float* desc_q, const float* desc_t,
+                     const float* norm_q, const float* norm_t,
+                     const int32_t* view_q, const int32_t* view_t,
+                     const int32_t* n_q, const int32_t* n_t,
+                     int B, int nq, int nt, int dim, int precision,
+                     int32_t* idx, float* d1sq, float* d2sq,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* Lowe ratio test, strict '<':  keep[i] = idx[i] >= 0 && second exists && d1 < ratio * d2.
+ * Hamming form compares d1 < ratio*d2 in f32; L2 form takes SQUARED distances and compares
+ * d1sq < ratio^2 * d2sq (== d1 < ratio*d2 on true distances).  n = B*nq elements. */
+int ph_ratio_filter_hamming(const int32_t* idx, const int32_t* d1, const int32_t* d2, int64_t n,
+                            float ratio, int32_t* keep, void* stream);
+int ph_ratio_filter_l2(const int32_t* idx, const float* d1sq, const float* d2sq, int64_t n,
+                       float ratio, int32_t* keep, void* stream);
+
+/* Stable compaction of kept matches into SoA correspondences.  kp_q / kp_t are keypoint tables
+ * [V][n_rows][2] (x,y) f32 in whatever coordinates the scorer wants (normalised for E).
+ * For pair b, every kept query i (in increasing i) appends (kp_q[i], kp_t[idx[i]]) to
+ * x1,y1,x2,y2 [B][nq] and match_q / match_t [B][nq] (may be NULL); n_match[b] = number kept. */
+int ph_compact_matches(const int32_t* idx, const int32_t* keep,
+                       const float* kp_q, const float* kp_t,
+                       const int32_t* view_q, const int32_t* view_t,
+                       int B, int nq, int nt,
+                       float* x1, float* y1, float* x2, float* y2,
+                       int32_t* match_q, int32_t* match_t, int32_t* n_match, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) RANSAC hypothesis scoring.                                    SURVEY.md §8 row a-10
+ *     PnP residual = the reference's reprojection error, validate_pose.py:260-288 (project,
+ *     per-point Euclidean pixel distance); the essential-matrix side has no reference code.
+ *     One launch scores H hypotheses against N correspondences for each of B items and
+ *     returns inlier counts; points are SoA rows of stride N; n_valid[b] (NULL = N) points
+ *     of item b are valid.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Sampson distance of (x1,y1)->(x2,y2) (normalised image coordinates) under E (row-major 9):
+ * inlier iff (x2' E x1)^2 < thr_sq * ((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2). */
+int ph_score_essential(const float* E, const float* x1, const float* y1,
+                       const float* x2, const float* y2, const int32_t* n_valid,
+                       int B, int H, int N, float thr_sq, int32_t* count, void* stream);
+
+/* Reprojection error of (X,Y,Z)->(u,v) under a 3x4 projection P (row-major 12; K[R|t] for
+ * pixel thresholds, [R|t] for normalised ones; (u,v) already undistorted):
+ * inlier iff w > 0 and (pu - u*w)^2 + (pv - v*w)^2 < thr_sq * w^2,  (pu,pv,w) = P [X Y Z 1]'. */
+int ph_score_pnp(const float* P, const float* X, const float* Y, const float* Z,
+                 const float* u, const float* v, const int32_t* n_valid,
+                 int B, int H, int N, float thr_sq, int32_t* count, void* stream);
+
+/* argmax over hypotheses, ties -> lowest hypothesis index.  best_idx/best_count are [B]. */
+int ph_select_best(const int32_t* count, int B, int H, int32_t* best_idx, int32_t* best_count,
+                   void* stream);
+
+/* Inlier mask of ONE model per item: model[b] = models + (sel ? sel[b] : 0)*stride floats
+ * inside item b's [H][stride] block (stride 9 / 12).  mask is [B][ceil(N/64)] 64-bit words,
+ * bit (i & 63) of word (i >> 6) = point i; bits >= n_valid[b] are zero. */
+int ph_inlier_mask_essential(const float* E, const int32_t* sel, int H,
+                             const float* x1, const float* y1, const float* x2, const float* y2,
+                             const int32_t* n_valid, int B, int N, float thr_sq,
+                             uint64_t* mask, void* stream);
+int ph_inlier_mask_pnp(const float* P, const int32_t* sel, int H,
+                       const float* X, const float* Y, const float* Z,
+                       const float* u, const float* v,
+                       const int32_t* n_valid, int B, int N, float thr_sq,
+                       uint64_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (3) Batched linear (DLT) triangulation.                           SURVEY.md §8 row a-11
+ *     Rows x*P[2]-P[0], y*P[2]-P[1] for both views; the solution is the eigenvector of the
+ *     smallest eigenvalue of A'A (= smallest right singular vector of A), de-homogenised.
+ *     P1/P2 are [B][C][12]: C candidate second-view/first-view projection pairs per item
+ *     (C = 1 for plain triangulation, 4 for recoverPose-style cheirality voting).
+ *     XYZ is [B][C][N][3] (may be NULL when only the vote is wanted); front[B][C] (may be
+ *     NULL) counts points with positive depth in BOTH views among points whose bit is set in
+ *     `mask` ([B][ceil(N/64)], NULL = all valid points).
+ * ------------------------------------------------------------------------------------------ */
+int ph_triangulate(const float* P1, const float* P2,
+                   const float* x1, const float* y1, const float* x2, const float* y2,
+                   const int32_t* n_valid, const uint64_t* mask,
+                   int B, int C, int N, float* XYZ, int32_t* front, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (4) Board-pose helpers: the reference's own arithmetic, batched.
+ * ------------------------------------------------------------------------------------------ */
+
+/* cv2.projectPoints with the 5-coefficient model (k1,k2,p1,p2,k3), validate_pose.py:181-184
+ * and :275.  Computed in float64 like the reference (rvec, tvec, K, dist are float64 there,
+ * main.py:28-34).  pose is [B][6] = rvec(3), tvec(3); K4 = fx,fy,cx,cy; obj is [B][N][3] f32
+ * (matchImagePoints hands back float32); uv is [B][N][2] f64 (may be NULL); uv_int (may be
+ * NULL) is the reference's astype(int32), i.e. truncation toward zero. */
+int ph_project_points(const float* obj, const double* pose, const double* K4, const double* dist5,
+                      const int32_t* n_valid, int B, int N,
+                      double* uv, int32_t* uv_int, void* stream);
+
+/* calculate_reprojection_error, validate_pose.py:260-288: per-point error err[B][N] (may be
+ * NULL) and the five statistics stats[B][5] = mean, std (ddof 0), max, min, num_points. */
+int ph_reprojection_error(const float* obj, const float* img, const double* pose,
+                          const double* K4, const double* dist5, const int32_t* n_valid,
+                          int B, int N, double* err, double* stats, void* stream);
+
+/* Inverse of the distortion model for 2-D points (pixels [n][2] f32 -> normalised, undistorted
+ * [n][2] f32), `iters` fixed-point iterations in float64: the one-off undistort ahead of
+ * ph_score_pnp / ph_score_essential. */
+int ph_undistort_points(const float* uv, const double* K4, const double* dist5,
+                        int64_t n, int iters, float* xy_norm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEHOT_H */

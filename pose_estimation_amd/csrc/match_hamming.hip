@@ -1,0 +1,208 @@
+// match_hamming.hip — brute-force 256-bit Hamming matcher, nearest + second nearest.
+// SURVEY.md §8 row a-9 (no reference code; contract in include/posehot.h).
+//
+// Layout of the work (one launch, B pairs):
+//   grid = (ceil(nq / (256*QPT)), splits, B), block = 256 threads = 4 waves.
+//   Every thread keeps QPT query descriptors (8 dwords each) in registers.  Train descriptors
+//   are staged through LDS in tiles of TT rows (register-prefetched double buffer); inside a
+//   tile every lane reads the SAME train row, so the two ds_read_b128 per row are broadcasts.
+//   Per (query, train) pair the VALU work is 8 xor + 8 popcount-accumulate (a 64-bit popcount
+//   is two 32-bit v_bcnt on this ISA) + 3 for the packed top-2 update:
+//       key = (distance << 22) + train_index      (one v_lshl_add_u32)
+//       m2  = med3(m1, m2, key);  m1 = min(m1, key)
+//   The key orders lexicographically by (distance, index): ties go to the lowest index.
+//   When the train set is split over blockIdx.y (few pairs, large sets) every split writes its
+//   (m1, m2) pair to the workspace and a second tiny kernel merges them.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kIdxBits = 22;                      // train rows per view < 2^22
+constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
+constexpr uint32_t kNoKey = 0xffffffffu;
+constexpr int kTT = 128;                          // train rows per LDS tile (4 KiB)
+
+__device__ __forceinline__ void top2_insert(uint32_t& m1, uint32_t& m2, uint32_t key) {
+    uint32_t med;                                  // m1 <= m2 always: med3 = new second-best
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(med) : "v"(m1), "v"(m2), "v"(key));
+    m2 = med;
+    m1 = min(m1, key);
+}
+
+__device__ __forceinline__ void emit(uint32_t m1, uint32_t m2, int32_t* idx, int32_t* d1, int32_t* d2, size_t o) {
+    idx[o] = (m1 == kNoKey) ? PH_NO_INDEX : (int32_t)(m1 & kIdxMask);
+    d1[o] = (m1 == kNoKey) ? PH_HAMMING_NONE : (int32_t)(m1 >> kIdxBits);
+    d2[o] = (m2 == kNoKey) ? PH_HAMMING_NONE : (int32_t)(m2 >> kIdxBits);
+}
+
+template <int QPT>
+__global__ __launch_bounds__(256) void hamming_top2_kernel(
+    const uint4* __restrict__ dq, const uint4* __restrict__ dt,
+    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
+    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
+    int nq, int nt, int splits, int rows_per_split,
+    int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
+    uint2* __restrict__ partial) {
+    __shared__ uint4 tile[2][kTT * 2];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, split = blockIdx.y;
+    const int q0 = blockIdx.x * (256 * QPT);
+    const int vq = view_q ? view_q[b] : b;
+    const int vt = view_t ? view_t[b] : b;
+    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const uint4* Q = dq + (size_t)vq * nq * 2;
+    const uint4* T = dt + (size_t)vt * nt * 2;
+
+    uint64_t qr[QPT][4];
+#pragma unroll
+    for (int p = 0; p < QPT; ++p) {
+        const int qi = q0 + p * 256 + tid;
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (qi < nqv) { a = Q[(size_t)qi * 2]; c = Q[(size_t)qi * 2 + 1]; }
+        qr[p][0] = ((uint64_t)a.y << 32) | a.x; qr[p][1] = ((uint64_t)a.w << 32) | a.z;
+        qr[p][2] = ((uint64_t)c.y << 32) | c.x; qr[p][3] = ((uint64_t)c.w << 32) | c.z;
+    }
+    uint32_t m1[QPT], m2[QPT];
+#pragma unroll
+    for (int p = 0; p < QPT; ++p) { m1[p] = kNoKey; m2[p] = kNoKey; }
+
+    const int t_begin = split * rows_per_split;
+    const int t_end = min(ntv, t_begin + rows_per_split);
+
+    // thread `tid` stages 16 B: half (tid & 1) of tile row (tid >> 1)
+    auto fetch = [&](int t0) -> uint4 {
+        const int row = t0 + (tid >> 1);
+        return (row < t_end) ? T[(size_t)row * 2 + (tid & 1)] : make_uint4(0, 0, 0, 0);
+    };
+
+    if (t_begin < t_end) {
+        uint4 stage = fetch(t_begin);
+        int cur = 0;
+        for (int t0 = t_begin; t0 < t_end; t0 += kTT) {
+            tile[cur][tid] = stage;
+            __syncthreads();                       // tile[cur] visible; tile[cur^1] free again
+            if (t0 + kTT < t_end) stage = fetch(t0 + kTT);
+            const int rows = min(kTT, t_end - t0);
+            const uint4* tl = tile[cur];
+#pragma unroll 4
+            for (int r = 0; r < rows; ++r) {
+                const uint4 a = tl[2 * r], c = tl[2 * r + 1];   // wave-uniform address: broadcast
+                const uint64_t w0 = ((uint64_t)a.y << 32) | a.x, w1 = ((uint64_t)a.w << 32) | a.z;
+                const uint64_t w2 = ((uint64_t)c.y << 32) | c.x, w3 = ((uint64_t)c.w << 32) | c.z;
+                const uint32_t j = (uint32_t)(t0 + r);
+#pragma unroll
+                for (int p = 0; p < QPT; ++p) {
+                    const uint32_t d = __popcll(qr[p][0] ^ w0) + __popcll(qr[p][1] ^ w1) +
+                                       __popcll(qr[p][2] ^ w2) + __popcll(qr[p][3] ^ w3);
+                    top2_insert(m1[p], m2[p], (d << kIdxBits) + j);
+                }
+            }
+            cur ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int p = 0; p < QPT; ++p) {
+        const int qi = q0 + p * 256 + tid;
+        if (qi >= nq) continue;
+        if (qi >= nqv) { m1[p] = kNoKey; m2[p] = kNoKey; }
+        if (splits == 1) emit(m1[p], m2[p], idx, d1, d2, (size_t)b * nq + qi);
+        else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(m1[p], m2[p]);
+    }
+}
+
+__global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2* __restrict__ partial, int B, int nq,
+                                                           int splits, int32_t* __restrict__ idx,
+                                                           int32_t* __restrict__ d1, int32_t* __restrict__ d2) {
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= (size_t)B * nq) return;
+    const size_t b = o / nq, i = o % nq;
+    uint32_t m1 = kNoKey, m2 = kNoKey;
+    for (int s = 0; s < splits; ++s) {
+        const uint2 p = partial[(b * splits + s) * nq + i];
+        top2_insert(m1, m2, p.x);
+        top2_insert(m1, m2, p.y);
+    }
+    emit(m1, m2, idx, d1, d2, o);
+}
+
+__global__ __launch_bounds__(256) void ratio_hamming_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ d1,
+                                                           const int32_t* __restrict__ d2, int64_t n, float ratio,
+                                                           int32_t* __restrict__ keep) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keep[i] = (idx[i] >= 0 && d2[i] != PH_HAMMING_NONE && (float)d1[i] < ratio * (float)d2[i]) ? 1 : 0;
+}
+
+// how to cut one launch: queries per thread and train splits, from the amount of work.
+struct HammingPlan { int qpt, splits, rows_per_split; };
+HammingPlan plan_hamming(int B, int nq, int nt) {
+    HammingPlan p;
+    const long waves_target = 256L * 4 * 4;                    // ~4 waves per SIMD over the chip
+    p.qpt = 4;
+    while (p.qpt > 1 && (long)B * ph_ceil_div(nq, 256 * p.qpt) * 4 < waves_target) p.qpt >>= 1;
+    const long blocks = (long)B * ph_ceil_div(nq, 256 * p.qpt);
+    int s = (int)((waves_target / 4 + blocks - 1) / blocks);
+    const int max_s = ph_ceil_div(nt, 4 * kTT);                // at least 4 tiles per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kTT) * kTT;
+    if (p.rows_per_split < kTT) p.rows_per_split = kTT;
+    p.splits = ph_ceil_div(nt, p.rows_per_split);
+    if (p.splits < 1) p.splits = 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t ph_match_hamming_ws_bytes(int B, int nq, int nt) {
+    if (B <= 0 || nq <= 0 || nt <= 0) return 0;
+    const HammingPlan p = plan_hamming(B, nq, nt);
+    return p.splits > 1 ? sizeof(uint2) * (size_t)B * p.splits * nq : 0;
+}
+
+extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_t,
+                                     const int32_t* view_q, const int32_t* view_t,
+                                     const int32_t* n_q, const int32_t* n_t,
+                                     int B, int nq, int nt, int bytes,
+                                     int32_t* idx, int32_t* d1, int32_t* d2,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
+    if (bytes != 32) return PH_ERR_UNSUPPORTED;
+    if (nt > (int)kIdxMask || B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || nq == 0) return PH_OK;
+    if (!desc_q || !idx || !d1 || !d2 || (nt > 0 && !desc_t)) return PH_ERR_INVALID_ARG;
+    if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HammingPlan p = (nt > 0) ? plan_hamming(B, nq, nt) : HammingPlan{1, 1, kTT};
+    if (p.splits > 1) {
+        if (!ws || ws_bytes < ph_match_hamming_ws_bytes(B, nq, nt) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
+    }
+    const dim3 grid(ph_ceil_div(nq, 256 * p.qpt), p.splits, B);
+    const uint4* q4 = (const uint4*)desc_q;
+    const uint4* t4 = (const uint4*)desc_t;
+    uint2* part = (uint2*)ws;
+#define PH_LAUNCH(QPT) hipLaunchKernelGGL(hamming_top2_kernel<QPT>, grid, dim3(256), 0, st, q4, t4, view_q, view_t, \
+                                          n_q, n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
+    if (p.qpt == 4) PH_LAUNCH(4); else if (p.qpt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
+#undef PH_LAUNCH
+    if (p.splits > 1) {
+        const size_t n = (size_t)B * nq;
+        hipLaunchKernelGGL(hamming_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, B, nq,
+                           p.splits, idx, d1, d2);
+    }
+    return ph_launch_status();
+}
+
+extern "C" int ph_ratio_filter_hamming(const int32_t* idx, const int32_t* d1, const int32_t* d2, int64_t n,
+                                       float ratio, int32_t* keep, void* stream) {
+    if (n < 0) return PH_ERR_INVALID_ARG;
+    if (n == 0) return PH_OK;
+    if (!idx || !d1 || !d2 || !keep) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(ratio_hamming_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       idx, d1, d2, n, ratio, keep);
+    return ph_launch_status();
+}

@@ -1,0 +1,250 @@
+// score.hip — RANSAC hypothesis scoring: Sampson error (essential matrix) and reprojection
+// error (PnP), inlier counts by wave ballot.  SURVEY.md §8 row a-10.  The PnP residual is the
+// reference's reprojection error (validate_pose.py:260-288) evaluated on undistorted points;
+// the essential-matrix side has no reference code (contract: include/posehot.h).
+//
+// Work cut: points live on the lanes (coalesced SoA loads, PPL points per lane held in
+// registers), the hypothesis is wave-uniform.  A wave owns HPW hypotheses and walks the point
+// range of its block in chunks of 64*PPL; per (hypothesis, chunk) it does PPL residual tests,
+// each followed by one 64-bit ballot whose popcount is added to a scalar counter.
+//   grid = (ceil(H / (4*HPW)), point_splits, B), block = 256 threads = 4 waves.
+// With one point split the counter is stored directly; with several (few items, many points)
+// the launch first zeroes count[] and the waves add their partial counts atomically (integer
+// adds: the result does not depend on arrival order).
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kHPW = 8;   // hypotheses per wave
+constexpr int kPPL = 8;   // points per lane per chunk
+
+// ---- the two residual tests; op order = DESIGN.md "Arithmetic contracts" -----------------
+__device__ __forceinline__ bool sampson_inlier(const float (&E)[9], float x1, float y1, float x2, float y2, float thr_sq) {
+    const float e0 = ph_fma(E[0], x1, ph_fma(E[1], y1, E[2]));
+    const float e1 = ph_fma(E[3], x1, ph_fma(E[4], y1, E[5]));
+    const float e2 = ph_fma(E[6], x1, ph_fma(E[7], y1, E[8]));
+    const float t0 = ph_fma(E[0], x2, ph_fma(E[3], y2, E[6]));
+    const float t1 = ph_fma(E[1], x2, ph_fma(E[4], y2, E[7]));
+    const float num = ph_fma(x2, e0, ph_fma(y2, e1, e2));
+    const float den = ph_fma(e0, e0, ph_fma(e1, e1, ph_fma(t0, t0, t1 * t1)));
+    return (num * num) < (thr_sq * den);
+}
+
+__device__ __forceinline__ bool pnp_inlier(const float (&P)[12], float X, float Y, float Z, float u, float v, float thr_sq) {
+    const float pu = ph_fma(P[0], X, ph_fma(P[1], Y, ph_fma(P[2], Z, P[3])));
+    const float pv = ph_fma(P[4], X, ph_fma(P[5], Y, ph_fma(P[6], Z, P[7])));
+    const float w = ph_fma(P[8], X, ph_fma(P[9], Y, ph_fma(P[10], Z, P[11])));
+    const float du = ph_fma(-u, w, pu);
+    const float dv = ph_fma(-v, w, pv);
+    const float e2 = ph_fma(du, du, dv * dv);
+    return (w > 0.0f) && (e2 < thr_sq * (w * w));
+}
+
+struct EssentialModel {
+    static constexpr int kParams = 9, kArrays = 4;
+    __device__ static __forceinline__ bool test(const float (&m)[9], const float (&p)[4], float thr_sq) {
+        return sampson_inlier(m, p[0], p[1], p[2], p[3], thr_sq);
+    }
+};
+struct PnpModel {
+    static constexpr int kParams = 12, kArrays = 5;
+    __device__ static __forceinline__ bool test(const float (&m)[12], const float (&p)[5], float thr_sq) {
+        return pnp_inlier(m, p[0], p[1], p[2], p[3], p[4], thr_sq);
+    }
+};
+
+template <int NA> struct PointArrays { const float* a[NA]; };
+
+template <class Model>
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ models, PointArrays<Model::kArrays> pts,
+                                                   const int32_t* __restrict__ n_valid, int H, int N, int psplits,
+                                                   int pts_per_split, float thr_sq, int32_t* __restrict__ count) {
+    constexpr int NP = Model::kParams, NA = Model::kArrays;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int h0 = (blockIdx.x * 4 + wave) * kHPW;
+    if (h0 >= H) return;                                   // wave-uniform; no barriers below
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    const int p_begin = blockIdx.y * pts_per_split;
+    const int p_end = min(nv, p_begin + pts_per_split);
+
+    int cnt[kHPW];
+#pragma unroll
+    for (int k = 0; k < kHPW; ++k) cnt[k] = 0;
+
+    const float* mb = models + ((size_t)b * H + h0) * NP;
+    const int nh = min(kHPW, H - h0);
+
+    for (int c0 = p_begin; c0 < p_end; c0 += 64 * kPPL) {
+        float pt[kPPL][NA];
+#pragma unroll
+        for (int p = 0; p < kPPL; ++p) {
+            const int i = c0 + p * 64 + lane;
+            const bool ok = i < p_end;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) pt[p][a] = ok ? pts.a[a][(size_t)b * N + i] : NAN;   // NaN never passes '<'
+        }
+#pragma unroll
+        for (int k = 0; k < kHPW; ++k) {
+            if (k < nh) {
+                float m[NP];
+#pragma unroll
+                for (int e = 0; e < NP; ++e) m[e] = mb[k * NP + e];            // wave-uniform address
+                int c = 0;
+#pragma unroll
+                for (int p = 0; p < kPPL; ++p) c += __popcll(__ballot(Model::test(m, pt[p], thr_sq)));
+                cnt[k] += c;
+            }
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kHPW; ++k) {
+            if (k < nh) {
+                int32_t* dst = count + (size_t)b * H + h0 + k;
+                if (psplits == 1) *dst = cnt[k]; else atomicAdd(dst, cnt[k]);
+            }
+        }
+    }
+}
+
+// one model per item -> 64-bit inlier words; one wave per 64 points.
+template <class Model>
+__global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ models, const int32_t* __restrict__ sel, int H,
+                                                  PointArrays<Model::kArrays> pts, const int32_t* __restrict__ n_valid,
+                                                  int N, int words, float thr_sq, uint64_t* __restrict__ mask) {
+    constexpr int NP = Model::kParams, NA = Model::kArrays;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= words) return;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    int s = sel ? sel[b] : 0;
+    s = min(max(s, 0), H - 1);
+    const float* mb = models + ((size_t)b * H + s) * NP;
+    float m[NP];
+#pragma unroll
+    for (int e = 0; e < NP; ++e) m[e] = mb[e];
+    const int i = w * 64 + lane;
+    float p[NA];
+#pragma unroll
+    for (int a = 0; a < NA; ++a) p[a] = (i < nv) ? pts.a[a][(size_t)b * N + i] : NAN;
+    const uint64_t bits = __ballot(Model::test(m, p, thr_sq));
+    if (lane == 0) mask[(size_t)b * words + w] = bits;
+}
+
+// argmax over hypotheses, ties -> lowest index: max over key = (count << 32) | ~h.
+__global__ __launch_bounds__(256) void select_best_kernel(const int32_t* __restrict__ count, int H,
+                                                         int32_t* __restrict__ best_idx, int32_t* __restrict__ best_count) {
+    __shared__ unsigned long long red[4];
+    const int b = blockIdx.x;
+    unsigned long long best = 0;
+    for (int hyp = threadIdx.x; hyp < H; hyp += 256) {
+        const unsigned long long key = ((unsigned long long)(uint32_t)max(count[(size_t)b * H + hyp], 0) << 32) |
+                                       (uint32_t)(0xffffffffu - (uint32_t)hyp);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o);
+        best = other > best ? other : best;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) best = red[k] > best ? red[k] : best;
+        if (H > 0) {
+            best_idx[b] = (int32_t)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+            best_count[b] = (int32_t)(best >> 32);
+        } else {
+            best_idx[b] = PH_NO_INDEX;
+            best_count[b] = 0;
+        }
+    }
+}
+
+struct ScorePlan { int psplits, pts_per_split; };
+ScorePlan plan_score(int B, int H, int N) {
+    ScorePlan p;
+    const long blocks = (long)B * ph_ceil_div(H, 4 * kHPW);
+    const long target = 1024;                                  // 4 blocks (16 waves) per CU
+    int s = (int)((target + blocks - 1) / blocks);
+    const int chunk = 64 * kPPL;
+    const int max_s = ph_ceil_div(N, 2 * chunk);
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    p.pts_per_split = ph_ceil_div(ph_ceil_div(N, s), chunk) * chunk;
+    p.psplits = ph_ceil_div(N, p.pts_per_split);
+    if (p.psplits < 1) p.psplits = 1;
+    return p;
+}
+
+template <class Model>
+int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int32_t* n_valid, int B, int H, int N,
+                 float thr_sq, int32_t* count, void* stream) {
+    if (B < 0 || H < 0 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || H == 0) return PH_OK;
+    if (!models || !count) return PH_ERR_INVALID_ARG;
+    for (int a = 0; a < Model::kArrays; ++a) if (N > 0 && !pts.a[a]) return PH_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const ScorePlan p = plan_score(B, H, N > 0 ? N : 1);
+    if (p.psplits > 1 || N == 0) {
+        if (hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)B * H, st) != hipSuccess) return PH_ERR_LAUNCH;
+        if (N == 0) return PH_OK;
+    }
+    const dim3 grid(ph_ceil_div(H, 4 * kHPW), p.psplits, B);
+    hipLaunchKernelGGL(score_kernel<Model>, grid, dim3(256), 0, st, models, pts, n_valid, H, N, p.psplits,
+                       p.pts_per_split, thr_sq, count);
+    return ph_launch_status();
+}
+
+template <class Model>
+int mask_launch(const float* models, const int32_t* sel, int H, PointArrays<Model::kArrays> pts, const int32_t* n_valid,
+                int B, int N, float thr_sq, uint64_t* mask, void* stream) {
+    if (B < 0 || H < 1 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || N == 0) return PH_OK;
+    if (!models || !mask) return PH_ERR_INVALID_ARG;
+    for (int a = 0; a < Model::kArrays; ++a) if (!pts.a[a]) return PH_ERR_INVALID_ARG;
+    const int words = ph_ceil_div(N, 64);
+    hipLaunchKernelGGL(mask_kernel<Model>, dim3(ph_ceil_div(words, 4), B), dim3(256), 0, (hipStream_t)stream, models, sel,
+                       H, pts, n_valid, N, words, thr_sq, mask);
+    return ph_launch_status();
+}
+
+}  // namespace
+
+extern "C" int ph_score_essential(const float* E, const float* x1, const float* y1, const float* x2, const float* y2,
+                                  const int32_t* n_valid, int B, int H, int N, float thr_sq, int32_t* count,
+                                  void* stream) {
+    return score_launch<EssentialModel>(E, PointArrays<4>{{x1, y1, x2, y2}}, n_valid, B, H, N, thr_sq, count, stream);
+}
+
+extern "C" int ph_score_pnp(const float* P, const float* X, const float* Y, const float* Z, const float* u,
+                            const float* v, const int32_t* n_valid, int B, int H, int N, float thr_sq, int32_t* count,
+                            void* stream) {
+    return score_launch<PnpModel>(P, PointArrays<5>{{X, Y, Z, u, v}}, n_valid, B, H, N, thr_sq, count, stream);
+}
+
+extern "C" int ph_select_best(const int32_t* count, int B, int H, int32_t* best_idx, int32_t* best_count, void* stream) {
+    if (B < 0 || H < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!best_idx || !best_count || (H > 0 && !count)) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, count, H, best_idx, best_count);
+    return ph_launch_status();
+}
+
+extern "C" int ph_inlier_mask_essential(const float* E, const int32_t* sel, int H, const float* x1, const float* y1,
+                                        const float* x2, const float* y2, const int32_t* n_valid, int B, int N,
+                                        float thr_sq, uint64_t* mask, void* stream) {
+    return mask_launch<EssentialModel>(E, sel, H, PointArrays<4>{{x1, y1, x2, y2}}, n_valid, B, N, thr_sq, mask, stream);
+}
+
+extern "C" int ph_inlier_mask_pnp(const float* P, const int32_t* sel, int H, const float* X, const float* Y,
+                                  const float* Z, const float* u, const float* v, const int32_t* n_valid, int B, int N,
+                                  float thr_sq, uint64_t* mask, void* stream) {
+    return mask_launch<PnpModel>(P, sel, H, PointArrays<5>{{X, Y, Z, u, v}}, n_valid, B, N, thr_sq, mask, stream);
+}

@@ -1,0 +1,172 @@
+// triangulate.hip — batched linear (DLT) triangulation and recoverPose-style cheirality vote.
+// SURVEY.md §8 row a-11 (no reference code; contract in include/posehot.h).
+//
+// One thread per (item, candidate, point).  The 4x4 system A (rows x*P[2]-P[0], y*P[2]-P[1] for
+// both views) is diagonalised in registers by a one-sided (Hestenes) Jacobi SVD — it works on A
+// itself, so the f32 result does not pay the squared condition number of A'A.  The right singular
+// vector of the smallest singular value is de-homogenised and stored; the depth signs in both
+// views feed a ballot-counted vote used by the host's essential-matrix decomposition.
+// HBM traffic per point: 16 B in (+ 96 B of P per item, L2-resident) and 12 B out.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kSweeps = 6;
+
+__device__ __forceinline__ void rotate_cols(float (&A)[4][4], float (&V)[4][4], int p, int q) {
+    float alpha = 0.f, beta = 0.f, gamma = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        alpha = ph_fma(A[r][p], A[r][p], alpha);
+        beta = ph_fma(A[r][q], A[r][q], beta);
+        gamma = ph_fma(A[r][p], A[r][q], gamma);
+    }
+    // rotation angle that zeroes the (p,q) inner product; t = tan(theta), |t| <= 1
+    const float zeta = (beta - alpha) * __frcp_rn(2.0f * gamma);
+    const float az = fabsf(zeta);
+    float t = __frcp_rn(az + __fsqrt_rn(ph_fma(zeta, zeta, 1.0f)));
+    t = (zeta < 0.0f) ? -t : t;
+    t = (gamma == 0.0f || !(az < INFINITY)) ? 0.0f : t;
+    const float c = __frsqrt_rn(ph_fma(t, t, 1.0f));
+    const float s = c * t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ap = A[r][p], aq = A[r][q];
+        A[r][p] = ph_fma(c, ap, -s * aq);
+        A[r][q] = ph_fma(s, ap, c * aq);
+        const float vp = V[r][p], vq = V[r][q];
+        V[r][p] = ph_fma(c, vp, -s * vq);
+        V[r][q] = ph_fma(s, vp, c * vq);
+    }
+}
+
+__global__ __launch_bounds__(256) void triangulate_kernel(const float* __restrict__ P1, const float* __restrict__ P2,
+                                                         const float* __restrict__ x1, const float* __restrict__ y1,
+                                                         const float* __restrict__ x2, const float* __restrict__ y2,
+                                                         const int32_t* __restrict__ n_valid, const uint64_t* __restrict__ mask,
+                                                         int C, int N, float* __restrict__ XYZ, int32_t* __restrict__ front) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    const bool ok = i < nv;
+    const float* pa = P1 + ((size_t)b * C + c) * 12;
+    const float* pb = P2 + ((size_t)b * C + c) * 12;
+    float Pa[12], Pb[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { Pa[e] = pa[e]; Pb[e] = pb[e]; }
+
+    const size_t o = (size_t)b * N + (ok ? i : 0);
+    const float u1 = x1[o], v1 = y1[o], u2 = x2[o], v2 = y2[o];
+
+    float A[4][4], V[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        A[0][k] = ph_fma(u1, Pa[8 + k], -Pa[k]);
+        A[1][k] = ph_fma(v1, Pa[8 + k], -Pa[4 + k]);
+        A[2][k] = ph_fma(u2, Pb[8 + k], -Pb[k]);
+        A[3][k] = ph_fma(v2, Pb[8 + k], -Pb[4 + k]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) V[r][k] = (r == k) ? 1.0f : 0.0f;
+    }
+#pragma unroll 1
+    for (int sweep = 0; sweep < kSweeps; ++sweep) {
+        rotate_cols(A, V, 0, 1); rotate_cols(A, V, 2, 3);
+        rotate_cols(A, V, 0, 2); rotate_cols(A, V, 1, 3);
+        rotate_cols(A, V, 0, 3); rotate_cols(A, V, 1, 2);
+    }
+    float best = INFINITY, hx = 0.f, hy = 0.f, hz = 0.f, hw = 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float n2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) n2 = ph_fma(A[r][k], A[r][k], n2);
+        const bool lt = n2 < best;
+        best = lt ? n2 : best;
+        hx = lt ? V[0][k] : hx; hy = lt ? V[1][k] : hy; hz = lt ? V[2][k] : hz; hw = lt ? V[3][k] : hw;
+    }
+    const float X = hx / hw, Y = hy / hw, Z = hz / hw;
+    if (ok && XYZ) {
+        float* dst = XYZ + (((size_t)b * C + c) * N + i) * 3;
+        dst[0] = X; dst[1] = Y; dst[2] = Z;
+    }
+    if (front) {
+        const float z1 = ph_fma(Pa[8], X, ph_fma(Pa[9], Y, ph_fma(Pa[10], Z, Pa[11])));
+        const float z2 = ph_fma(Pb[8], X, ph_fma(Pb[9], Y, ph_fma(Pb[10], Z, Pb[11])));
+        bool sel = ok;
+        if (mask && ok) sel = (mask[(size_t)b * ((N + 63) / 64) + (i >> 6)] >> (i & 63)) & 1ull;
+        const unsigned long long votes = __ballot(sel && z1 > 0.0f && z2 > 0.0f);
+        if ((threadIdx.x & 63) == 0 && votes) atomicAdd(front + (size_t)b * C + c, (int32_t)__popcll(votes));
+    }
+}
+
+// stable compaction of kept matches, one 256-thread block per pair.
+__global__ __launch_bounds__(256) void compact_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ keep,
+                                                     const float2* __restrict__ kp_q, const float2* __restrict__ kp_t,
+                                                     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
+                                                     int nq, int nt, float* __restrict__ x1, float* __restrict__ y1,
+                                                     float* __restrict__ x2, float* __restrict__ y2,
+                                                     int32_t* __restrict__ match_q, int32_t* __restrict__ match_t,
+                                                     int32_t* __restrict__ n_match) {
+    __shared__ int wave_tot[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vq = view_q ? view_q[b] : b, vt = view_t ? view_t[b] : b;
+    const float2* KQ = kp_q + (size_t)vq * nq;
+    const float2* KT = kp_t + (size_t)vt * nt;
+    int base = 0;
+    for (int i0 = 0; i0 < nq; i0 += 256) {
+        const int i = i0 + tid;
+        int j = PH_NO_INDEX;
+        bool k = false;
+        if (i < nq) { j = idx[(size_t)b * nq + i]; k = keep[(size_t)b * nq + i] != 0 && j >= 0 && j < nt; }
+        const unsigned long long bal = __ballot(k);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        if (k) {
+            const size_t o = (size_t)b * nq + off + before;
+            const float2 a = KQ[i], t = KT[j];
+            x1[o] = a.x; y1[o] = a.y; x2[o] = t.x; y2[o] = t.y;
+            if (match_q) match_q[o] = i;
+            if (match_t) match_t[o] = j;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) n_match[b] = base;
+}
+
+}  // namespace
+
+extern "C" int ph_triangulate(const float* P1, const float* P2, const float* x1, const float* y1, const float* x2,
+                              const float* y2, const int32_t* n_valid, const uint64_t* mask, int B, int C, int N,
+                              float* XYZ, int32_t* front, void* stream) {
+    if (B < 0 || C < 0 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535 || C > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || C == 0) return PH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (front && hipMemsetAsync(front, 0, sizeof(int32_t) * (size_t)B * C, st) != hipSuccess) return PH_ERR_LAUNCH;
+    if (N == 0) return PH_OK;
+    if (!P1 || !P2 || !x1 || !y1 || !x2 || !y2 || (!XYZ && !front)) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(triangulate_kernel, dim3(ph_ceil_div(N, 256), C, B), dim3(256), 0, st, P1, P2, x1, y1, x2, y2,
+                       n_valid, mask, C, N, XYZ, front);
+    return ph_launch_status();
+}
+
+extern "C" int ph_compact_matches(const int32_t* idx, const int32_t* keep, const float* kp_q, const float* kp_t,
+                                  const int32_t* view_q, const int32_t* view_t, int B, int nq, int nt, float* x1,
+                                  float* y1, float* x2, float* y2, int32_t* match_q, int32_t* match_t, int32_t* n_match,
+                                  void* stream) {
+    if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!n_match) return PH_ERR_INVALID_ARG;
+    if (nq > 0 && (!idx || !keep || !kp_q || !x1 || !y1 || !x2 || !y2 || (nt > 0 && !kp_t))) return PH_ERR_INVALID_ARG;
+    if (!ph_aligned(kp_q, 8) || !ph_aligned(kp_t, 8)) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, idx, keep, (const float2*)kp_q,
+                       (const float2*)kp_t, view_q, view_t, nq, nt, x1, y1, x2, y2, match_q, match_t, n_match);
+    return ph_launch_status();
+}

@@ -1,0 +1,100 @@
+"""RANSAC hypothesis scoring on the GPU.
+
+PnP residual = the reference's reprojection error (validate_pose.py:260-288) on undistorted
+points; the essential-matrix (Sampson) side has no reference code.  Inputs are SoA point rows
+``[B, N]`` float32 and models ``[B, H, 9]`` (E, row-major) or ``[B, H, 12]`` (3x4 projection).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _pts(arrs, names):
+    out = [L.dev(a, torch.float32, n) for a, n in zip(arrs, names)]
+    shp = out[0].shape
+    if len(shp) != 2 or any(a.shape != shp for a in out):
+        raise ValueError("point arrays must share one [B, N] shape")
+    return out
+
+
+def _models(m, B, width, name):
+    m = L.dev(m, torch.float32, name)
+    if m.dim() != 3 or m.shape[0] != B or m.shape[2] != width:
+        raise ValueError(f"{name}: expected [B={B}, H, {width}], got {tuple(m.shape)}")
+    return m
+
+
+def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None):
+    """Inlier count of every E hypothesis (Sampson error < thr).  Returns int32 ``[B, H]``."""
+    lib = L.load()
+    x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
+    B, N = x1.shape
+    E = _models(E, B, 9, "E")
+    H = E.shape[1]
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    count = torch.empty((B, H), dtype=torch.int32, device=E.device)
+    L.check(lib.ph_score_essential(L.ptr(E), L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(n_valid),
+                                   B, H, N, float(thr_sq), L.ptr(count), L.stream_ptr()), "ph_score_essential")
+    return count
+
+
+def score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid=None):
+    """Inlier count of every 3x4 projection hypothesis.  Returns int32 ``[B, H]``."""
+    lib = L.load()
+    X, Y, Z, u, v = _pts((X, Y, Z, u, v), ("X", "Y", "Z", "u", "v"))
+    B, N = X.shape
+    P = _models(P, B, 12, "P")
+    H = P.shape[1]
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    count = torch.empty((B, H), dtype=torch.int32, device=P.device)
+    L.check(lib.ph_score_pnp(L.ptr(P), L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(n_valid),
+                             B, H, N, float(thr_sq), L.ptr(count), L.stream_ptr()), "ph_score_pnp")
+    return count
+
+
+def select_best(count):
+    """argmax over hypotheses, ties to the lowest index.  Returns (best_idx, best_count) int32 ``[B]``."""
+    lib = L.load()
+    count = L.dev(count, torch.int32, "count")
+    B, H = count.shape
+    bi = torch.empty((B,), dtype=torch.int32, device=count.device)
+    bc = torch.empty_like(bi)
+    L.check(lib.ph_select_best(L.ptr(count), B, H, L.ptr(bi), L.ptr(bc), L.stream_ptr()), "ph_select_best")
+    return bi, bc
+
+
+def inlier_mask_essential(E, sel, x1, y1, x2, y2, thr_sq, n_valid=None):
+    """64-bit inlier words ``[B, ceil(N/64)]`` (int64 tensor holding the bit patterns) of model sel[b]."""
+    lib = L.load()
+    x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
+    B, N = x1.shape
+    E = _models(E, B, 9, "E")
+    sel = L.opt_i32(sel, B, "sel")
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    mask = torch.zeros((B, (N + 63) // 64), dtype=torch.int64, device=E.device)
+    L.check(lib.ph_inlier_mask_essential(L.ptr(E), L.ptr(sel), E.shape[1], L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2),
+                                         L.ptr(n_valid), B, N, float(thr_sq), L.ptr(mask), L.stream_ptr()),
+            "ph_inlier_mask_essential")
+    return mask
+
+
+def inlier_mask_pnp(P, sel, X, Y, Z, u, v, thr_sq, n_valid=None):
+    lib = L.load()
+    X, Y, Z, u, v = _pts((X, Y, Z, u, v), ("X", "Y", "Z", "u", "v"))
+    B, N = X.shape
+    P = _models(P, B, 12, "P")
+    sel = L.opt_i32(sel, B, "sel")
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    mask = torch.zeros((B, (N + 63) // 64), dtype=torch.int64, device=P.device)
+    L.check(lib.ph_inlier_mask_pnp(L.ptr(P), L.ptr(sel), P.shape[1], L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v),
+                                   L.ptr(n_valid), B, N, float(thr_sq), L.ptr(mask), L.stream_ptr()),
+            "ph_inlier_mask_pnp")
+    return mask
+
+
+def unpack_mask(mask, N):
+    """[B, words] int64 bit words -> bool [B, N] (host-side convenience for tests and reports)."""
+    bits = torch.arange(64, device=mask.device, dtype=torch.int64)
+    return ((mask.unsqueeze(-1) >> bits) & 1).bool().reshape(mask.shape[0], -1)[:, :N]
