@@ -1,0 +1,57 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard a pair list and gather the pose table."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pose_estimation_amd import sharding
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_items, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ids = sharding.shard_indices(n_items, rank, world)
+    assert len(ids) == sharding.shard_size(n_items, rank, world)
+    local = torch.stack([ids.float() * 10 + c for c in range(16)], dim=1) if len(ids) else torch.zeros((0, 16))
+    full = sharding.gather_pose_table(local, n_items)
+    q.put((rank, full))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 8, 1])
+def test_shard_and_gather_world2(n_items):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = torch.stack([torch.arange(n_items).float() * 10 + c for c in range(16)], dim=1)
+    for r in range(world):
+        assert torch.equal(got[r], want)
+
+
+def test_shard_indices_cover_everything_once():
+    for n, w in [(4950, 8), (10, 3), (0, 2), (5, 8)]:
+        seen = torch.cat([sharding.shard_indices(n, r, w) for r in range(w)])
+        assert sorted(seen.tolist()) == list(range(n))
+
+
+def test_gather_without_process_group_is_identity():
+    t = torch.ones((3, 16))
+    assert sharding.gather_pose_table(t, 3) is t
