@@ -116,6 +116,23 @@ int ph_compact_matches(const int32_t* idx, const int32_t* keep,
  *     of item b are valid.
  * ------------------------------------------------------------------------------------------ */
 
+/* Minimal-sample indices, counter-based so CPU and GPU draw identical sample sets (north_star:
+ * "with identical RANSAC sample sets"): sample s of item b holds m (<= 8) distinct indices in
+ * [0, n_valid[b]); draw t is word 0 of Philox4x32-10(counter = (s, t, 0, 0), key = (seed, b)) mapped by
+ * idx = (word * n_valid) >> 32, repeated indices skipped.  samples is [B][S][m]; n_valid < m -> -1.
+ * No reference counterpart (the reference has no RANSAC); SURVEY.md §7 "Counter-based RNG". */
+int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, int N, int S, int m,
+                      int32_t* samples, void* stream);
+
+/* Nister 5-point essential-matrix solver, one minimal sample per thread (float64 inside).
+ * samples is [B][S][5] (indices into the item's N correspondences, normalised coordinates).
+ * E is [B][S*10][9] f32: sample s owns hypothesis slots 10s .. 10s+9; each real solution is a
+ * unit-Frobenius-norm E, unused slots are all-zero (they score zero inliers).  n_solutions
+ * ([B][S], may be NULL) = number of real solutions of each sample.  SURVEY.md §8f item 1. */
+int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
+                           const int32_t* samples, int B, int S, int N,
+                           float* E, int32_t* n_solutions, void* stream);
+
 /* Sampson distance of (x1,y1)->(x2,y2) (normalised image coordinates) under E (row-major 9):
  * inlier iff (x2' E x1)^2 < thr_sq * ((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2). */
 int ph_score_essential(const float* E, const float* x1, const float* y1,

@@ -1,0 +1,104 @@
+// fivepoint.hip — RANSAC hypothesis generation on the device: counter-based minimal sampling
+// (Philox4x32-10) and Nistér's 5-point essential-matrix solver.  SURVEY.md §8f item 1: there is
+// no reference code (main.py only calls cv2.solvePnP); the algebra is the published one
+// (D. Nistér, "An efficient solution to the five-point relative pose problem", PAMI 2004).
+//
+// One thread per minimal sample, float64 in private memory: null space of the 5x9 epipolar system
+// (Gauss-Jordan, full pivoting, re-orthonormalised) -> the 10 cubic constraints det(E) = 0 and
+// 2EE'E - tr(EE')E = 0 as a 10x20 coefficient matrix -> Gauss-Jordan -> 3x3 polynomial matrix in z
+// -> degree-10 determinant -> all roots by Aberth-Ehrlich iteration -> for every real root the E it
+// defines, unit Frobenius norm, stored as f32 in one of the sample's 10 hypothesis slots (unused
+// slots are all-zero matrices, which score zero inliers).
+#include <math.h>
+
+#include "common.hpp"
+#include "fivepoint_core.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- Philox4x32-10 (Salmon et al. 2011)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+}
+__device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1) {
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c[0];
+}
+
+// sample s of item b: m distinct indices in [0, n_valid[b]); draw t = Philox(counter (s,t,0,0), key (seed,b))
+// word 0 mapped by multiply-shift; a repeated index is skipped.  n_valid < m -> -1.
+__global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const int32_t* __restrict__ n_valid, int N, int S, int m,
+                                                    int32_t* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    int32_t* o = out + ((size_t)b * S + s) * m;
+    if (nv < m) { for (int k = 0; k < m; ++k) o[k] = -1; return; }
+    int got[8];
+    int n = 0;
+    for (uint32_t t = 0; n < m; ++t) {
+        const uint32_t w = philox_word0((uint32_t)s, t, seed, (uint32_t)b);
+        const int idx = (int)(((uint64_t)w * (uint64_t)nv) >> 32);
+        bool dup = false;
+        for (int k = 0; k < n; ++k) dup |= (got[k] == idx);
+        if (!dup) got[n++] = idx;
+    }
+    for (int k = 0; k < m; ++k) o[k] = got[k];
+}
+
+__global__ __launch_bounds__(64) void fivepoint_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+                                                      const float* __restrict__ x2, const float* __restrict__ y2,
+                                                      const int32_t* __restrict__ samples, int S, int N,
+                                                      float* __restrict__ E_out, int32_t* __restrict__ n_sol) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    float* eo = E_out + ((size_t)b * S + s) * 90;
+    for (int k = 0; k < 90; ++k) eo[k] = 0.0f;
+    if (n_sol) n_sol[(size_t)b * S + s] = 0;
+    const int32_t* si = samples + ((size_t)b * S + s) * 5;
+
+    double pts[5][4];
+    for (int r = 0; r < 5; ++r) {
+        const int i = si[r];
+        if (i < 0 || i >= N) return;
+        const size_t o = (size_t)b * N + i;
+        pts[r][0] = x1[o]; pts[r][1] = y1[o]; pts[r][2] = x2[o]; pts[r][3] = y2[o];
+    }
+    const int ns = ph5::solve_fivepoint(pts, eo);
+    if (n_sol) n_sol[(size_t)b * S + s] = ns;
+}
+
+}  // namespace
+
+extern "C" int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, int N, int S, int m, int32_t* samples,
+                                 void* stream) {
+    if (B < 0 || N < 0 || S < 0 || m < 1 || m > 8) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || S == 0) return PH_OK;
+    if (!samples) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(sample_kernel, dim3(ph_ceil_div(S, 256), B), dim3(256), 0, (hipStream_t)stream, seed, n_valid, N, S,
+                       m, samples);
+    return ph_launch_status();
+}
+
+extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
+                                      const int32_t* samples, int B, int S, int N, float* E, int32_t* n_solutions,
+                                      void* stream) {
+    if (B < 0 || S < 0 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || S == 0) return PH_OK;
+    if (!x1 || !y1 || !x2 || !y2 || !samples || !E) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(fivepoint_kernel, dim3(ph_ceil_div(S, 64), B), dim3(64), 0, (hipStream_t)stream, x1, y1, x2, y2,
+                       samples, S, N, E, n_solutions);
+    return ph_launch_status();
+}

@@ -1,0 +1,261 @@
+// fivepoint_core.hpp — Nister 5-point solver for ONE minimal sample (float64), shared by the device
+// kernel (fivepoint.hip) and a host debug harness; see fivepoint.hip for the algorithm summary.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#if defined(__HIPCC__)
+#define PH_HD __host__ __device__
+#else
+#define PH_HD
+#endif
+#define PH_HD_CONST static constexpr
+
+namespace ph5 {
+
+// ---------------------------------------------------------------- polynomial tables (tools/gen_poly_tables.py)
+// degree-1 monomials: x y z 1; degree-2: xx xy xz yy yz zz x y z 1; degree-3 graded (20).
+PH_HD_CONST int8_t kMul11[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+PH_HD_CONST int8_t kMul21[10][4] = {{0, 1, 2, 10}, {1, 3, 4, 11}, {2, 4, 5, 12}, {3, 6, 7, 13}, {4, 7, 8, 14},
+                                     {5, 8, 9, 15}, {10, 11, 12, 16}, {11, 13, 14, 17}, {12, 14, 15, 18}, {16, 17, 18, 19}};
+// column c of the elimination matrix (Nistér's order x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1)
+PH_HD_CONST int8_t kNister[20] = {0, 6, 1, 3, 2, 10, 7, 13, 4, 11, 5, 12, 16, 8, 14, 17, 9, 15, 18, 19};
+
+PH_HD inline void mul11_acc(const double* a, const double* b, double s, double* out) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[kMul11[i][j]] += s * a[i] * b[j];
+}
+PH_HD inline void mul21_acc(const double* a, const double* b, double s, double* out) {
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 4; ++j) out[kMul21[i][j]] += s * a[i] * b[j];
+}
+// c (ascending, length na+nb-1) += s * a * b
+PH_HD inline void pmul_acc(const double* a, int na, const double* b, int nb, double s, double* c) {
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) c[i + j] += s * a[i] * b[j];
+}
+
+struct cplx { double re, im; };
+PH_HD inline cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+PH_HD inline cplx cdiv(cplx a, cplx b) {
+    const double d = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+
+
+// pts[r] = (x1, y1, x2, y2) of correspondence r; eo = 90 floats (10 slots), pre-zeroed by the caller.
+// Returns the number of real solutions written.
+PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
+    // ---- 1. epipolar rows q . vec(E) = x2' E x1
+    double Q[5][9];
+    for (int r = 0; r < 5; ++r) {
+        const double a = pts[r][0], c = pts[r][1], d = pts[r][2], e = pts[r][3];
+        Q[r][0] = d * a; Q[r][1] = d * c; Q[r][2] = d; Q[r][3] = e * a; Q[r][4] = e * c; Q[r][5] = e;
+        Q[r][6] = a; Q[r][7] = c; Q[r][8] = 1.0;
+    }
+    // ---- 2. null space: Gauss-Jordan with full pivoting, then modified Gram-Schmidt
+    int perm[9];
+    for (int j = 0; j < 9; ++j) perm[j] = j;
+    for (int r = 0; r < 5; ++r) {
+        int pi = r, pj = r;
+        double best = -1.0;
+        for (int i = r; i < 5; ++i)
+            for (int j = r; j < 9; ++j) { const double v = fabs(Q[i][perm[j]]); if (v > best) { best = v; pi = i; pj = j; } }
+        if (!(best > 1e-12)) return 0;                                   // degenerate sample
+        if (pi != r) for (int j = 0; j < 9; ++j) { const double t = Q[r][j]; Q[r][j] = Q[pi][j]; Q[pi][j] = t; }
+        { const int t = perm[r]; perm[r] = perm[pj]; perm[pj] = t; }
+        const double inv = 1.0 / Q[r][perm[r]];
+        for (int j = 0; j < 9; ++j) Q[r][j] *= inv;
+        for (int i = 0; i < 5; ++i) {
+            if (i == r) continue;
+            const double f = Q[i][perm[r]];
+            for (int j = 0; j < 9; ++j) Q[i][j] -= f * Q[r][j];
+        }
+    }
+    double basis[4][9];
+    for (int k = 0; k < 4; ++k) {
+        for (int j = 0; j < 9; ++j) basis[k][j] = 0.0;
+        basis[k][perm[5 + k]] = 1.0;
+        for (int i = 0; i < 5; ++i) basis[k][perm[i]] = -Q[i][perm[5 + k]];
+    }
+    for (int k = 0; k < 4; ++k) {
+        for (int p = 0; p < k; ++p) {
+            double d = 0.0;
+            for (int j = 0; j < 9; ++j) d += basis[k][j] * basis[p][j];
+            for (int j = 0; j < 9; ++j) basis[k][j] -= d * basis[p][j];
+        }
+        double n2 = 0.0;
+        for (int j = 0; j < 9; ++j) n2 += basis[k][j] * basis[k][j];
+        const double inv = 1.0 / sqrt(n2);
+        for (int j = 0; j < 9; ++j) basis[k][j] *= inv;
+    }
+    // ---- 3. E entries as linear polynomials in (x, y, z, 1)
+    double Ep[9][4];
+    for (int e = 0; e < 9; ++e)
+        for (int k = 0; k < 4; ++k) Ep[e][k] = basis[k][e];
+    // ---- 4. EE' (symmetric, 6 entries) and its trace, degree 2
+    double EEt[3][3][10];
+    for (int r = 0; r < 3; ++r)
+        for (int c = r; c < 3; ++c) {
+            for (int k = 0; k < 10; ++k) EEt[r][c][k] = 0.0;
+            for (int k = 0; k < 3; ++k) mul11_acc(Ep[3 * r + k], Ep[3 * c + k], 1.0, EEt[r][c]);
+        }
+    for (int r = 1; r < 3; ++r)
+        for (int c = 0; c < r; ++c)
+            for (int k = 0; k < 10; ++k) EEt[r][c][k] = EEt[c][r][k];
+    double tr[10];
+    for (int k = 0; k < 10; ++k) tr[k] = EEt[0][0][k] + EEt[1][1][k] + EEt[2][2][k];
+    // ---- 5. the 10 cubic constraints, columns in Nistér's order
+    double A[10][20];
+    {
+        double tmp[20], d2[10];
+        auto put = [&](int row) { for (int c = 0; c < 20; ++c) A[row][c] = tmp[kNister[c]]; };
+        for (int k = 0; k < 20; ++k) tmp[k] = 0.0;
+        const int cof[3][4] = {{1, 5, 2, 4}, {2, 3, 0, 5}, {0, 4, 1, 3}};   // det E = sum_c (minor_c) * E[2][c]
+        for (int c = 0; c < 3; ++c) {
+            for (int k = 0; k < 10; ++k) d2[k] = 0.0;
+            mul11_acc(Ep[cof[c][0]], Ep[cof[c][1]], 1.0, d2);
+            mul11_acc(Ep[cof[c][2]], Ep[cof[c][3]], -1.0, d2);
+            mul21_acc(d2, Ep[6 + c], 1.0, tmp);
+        }
+        put(0);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                for (int k = 0; k < 20; ++k) tmp[k] = 0.0;
+                for (int k = 0; k < 3; ++k) mul21_acc(EEt[r][k], Ep[3 * k + c], 2.0, tmp);
+                mul21_acc(tr, Ep[3 * r + c], -1.0, tmp);
+                put(1 + 3 * r + c);
+            }
+    }
+    // ---- 6. Gauss-Jordan on the left 10x10 block (partial pivoting)
+    for (int c = 0; c < 10; ++c) {
+        int p = c;
+        double best = fabs(A[c][c]);
+        for (int i = c + 1; i < 10; ++i) { const double v = fabs(A[i][c]); if (v > best) { best = v; p = i; } }
+        if (!(best > 1e-14)) return 0;
+        if (p != c) for (int j = 0; j < 20; ++j) { const double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+        const double inv = 1.0 / A[c][c];
+        for (int j = c; j < 20; ++j) A[c][j] *= inv;
+        for (int i = 0; i < 10; ++i) {
+            if (i == c) continue;
+            const double f = A[i][c];
+            if (f != 0.0) for (int j = c; j < 20; ++j) A[i][j] -= f * A[c][j];
+        }
+    }
+    // ---- 7. k = e - z f, l = g - z h, m = i - z j  (ascending powers of z; x, y parts degree 3, 1 part degree 4)
+    double Bx[3][4], By[3][4], B1[3][5];
+    for (int q = 0; q < 3; ++q) {
+        const double* p = &A[4 + 2 * q][10];
+        const double* r = &A[5 + 2 * q][10];
+        Bx[q][3] = -r[0]; Bx[q][2] = p[0] - r[1]; Bx[q][1] = p[1] - r[2]; Bx[q][0] = p[2];
+        By[q][3] = -r[3]; By[q][2] = p[3] - r[4]; By[q][1] = p[4] - r[5]; By[q][0] = p[5];
+        B1[q][4] = -r[6]; B1[q][3] = p[6] - r[7]; B1[q][2] = p[7] - r[8]; B1[q][1] = p[8] - r[9]; B1[q][0] = p[9];
+    }
+    // ---- 8. det B(z), degree 10
+    double c[11];
+    for (int k = 0; k < 11; ++k) c[k] = 0.0;
+    {
+        double t7[8], t6[7];
+        for (int k = 0; k < 8; ++k) t7[k] = 0.0;
+        pmul_acc(By[1], 4, B1[2], 5, 1.0, t7); pmul_acc(B1[1], 5, By[2], 4, -1.0, t7);
+        pmul_acc(Bx[0], 4, t7, 8, 1.0, c);
+        for (int k = 0; k < 8; ++k) t7[k] = 0.0;
+        pmul_acc(Bx[1], 4, B1[2], 5, 1.0, t7); pmul_acc(B1[1], 5, Bx[2], 4, -1.0, t7);
+        pmul_acc(By[0], 4, t7, 8, -1.0, c);
+        for (int k = 0; k < 7; ++k) t6[k] = 0.0;
+        pmul_acc(Bx[1], 4, By[2], 4, 1.0, t6); pmul_acc(By[1], 4, Bx[2], 4, -1.0, t6);
+        pmul_acc(B1[0], 5, t6, 7, 1.0, c);
+    }
+    // ---- 9. all roots by Aberth-Ehrlich
+    int n = 10;
+    double cmax = 0.0;
+    for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(c[k]));
+    if (!(cmax > 0.0) || !(cmax < HUGE_VAL)) return 0;
+    while (n > 0 && fabs(c[n]) <= 1e-30 * cmax) --n;
+    if (n < 1) return 0;
+    cplx z[10];
+    {
+        double rad = pow(fabs(c[0] / c[n]) + 1e-300, 1.0 / n);
+        rad = fmin(fmax(rad, 1e-3), 1e3);
+        for (int k = 0; k < n; ++k) {
+            double sn, cs;
+            sn = sin(6.283185307179586 * k / n + 0.4); cs = cos(6.283185307179586 * k / n + 0.4);
+            z[k] = {rad * cs, rad * sn};
+        }
+    }
+    for (int it = 0; it < 100; ++it) {
+        double worst = 0.0;
+        for (int k = 0; k < n; ++k) {
+            cplx p = {c[n], 0.0}, dp = {0.0, 0.0};
+            for (int j = n - 1; j >= 0; --j) {
+                dp = cmul(dp, z[k]); dp.re += p.re; dp.im += p.im;
+                p = cmul(p, z[k]); p.re += c[j];
+            }
+            if (p.re == 0.0 && p.im == 0.0) continue;
+            const cplx nw = cdiv(p, dp);                      // Newton step
+            cplx sum = {0.0, 0.0};
+            for (int j = 0; j < n; ++j) {
+                if (j == k) continue;
+                const cplx d = {z[k].re - z[j].re, z[k].im - z[j].im};
+                const cplx inv = cdiv(cplx{1.0, 0.0}, d);
+                sum.re += inv.re; sum.im += inv.im;
+            }
+            const cplx den = {1.0 - (nw.re * sum.re - nw.im * sum.im), -(nw.re * sum.im + nw.im * sum.re)};
+            const cplx w = cdiv(nw, den);
+            if (w.re == w.re && w.im == w.im) {
+                z[k].re -= w.re; z[k].im -= w.im;
+                worst = fmax(worst, (fabs(w.re) + fabs(w.im)) / (fabs(z[k].re) + fabs(z[k].im) + 1e-30));
+            }
+        }
+        if (worst < 1e-15) break;
+    }
+#ifdef PH5_DEBUG
+    printf("n=%d coeffs:", n); for (int k = 0; k <= n; ++k) printf(" %.17g", c[k]); printf("\nroots:");
+    for (int k = 0; k < n; ++k) printf(" (%.12g,%.3g)", z[k].re, z[k].im); printf("\n");
+#endif
+    // ---- 10. real roots -> (x, y) from the null vector of B(z) -> E
+    int ns = 0;
+    for (int k = 0; k < n && ns < 10; ++k) {
+        if (!(fabs(z[k].im) < 1e-6 * fmax(1.0, fabs(z[k].re)))) continue;
+        double zr = z[k].re;
+        for (int it = 0; it < 6; ++it) {                       // polish on the real axis
+            double p = c[n], dp = 0.0;
+            for (int j = n - 1; j >= 0; --j) { dp = dp * zr + p; p = p * zr + c[j]; }
+            if (dp != 0.0) zr -= p / dp;
+        }
+        {   // a complex pair with a tiny imaginary part is not a solution: require p(zr) = 0 to rounding
+            double p = c[n], mag = fabs(c[n]);
+            const double az = fabs(zr);
+            for (int j = n - 1; j >= 0; --j) { p = p * zr + c[j]; mag = mag * az + fabs(c[j]); }
+            if (!(fabs(p) <= 1e-10 * mag)) continue;
+        }
+        double Bz[3][3];
+        for (int q = 0; q < 3; ++q) {
+            Bz[q][0] = ((Bx[q][3] * zr + Bx[q][2]) * zr + Bx[q][1]) * zr + Bx[q][0];
+            Bz[q][1] = ((By[q][3] * zr + By[q][2]) * zr + By[q][1]) * zr + By[q][0];
+            Bz[q][2] = (((B1[q][4] * zr + B1[q][3]) * zr + B1[q][2]) * zr + B1[q][1]) * zr + B1[q][0];
+        }
+        double v[3] = {0, 0, 0}, vbest = -1.0;                 // null vector = largest cross product of two rows
+        for (int q = 0; q < 3; ++q) {
+            const double* a = Bz[q];
+            const double* d = Bz[(q + 1) % 3];
+            const double w0 = a[1] * d[2] - a[2] * d[1], w1 = a[2] * d[0] - a[0] * d[2], w2 = a[0] * d[1] - a[1] * d[0];
+            const double nn = w0 * w0 + w1 * w1 + w2 * w2;
+            if (nn > vbest) { vbest = nn; v[0] = w0; v[1] = w1; v[2] = w2; }
+        }
+        if (!(fabs(v[2]) > 1e-14 * sqrt(vbest))) continue;
+        const double xr = v[0] / v[2], yr = v[1] / v[2];
+        double E[9], n2 = 0.0;
+        for (int e = 0; e < 9; ++e) {
+            E[e] = xr * basis[0][e] + yr * basis[1][e] + zr * basis[2][e] + basis[3][e];
+            n2 += E[e] * E[e];
+        }
+        if (!(n2 > 0.0) || !(n2 < HUGE_VAL)) continue;
+        const double inv = 1.0 / sqrt(n2);
+        for (int e = 0; e < 9; ++e) eo[9 * ns + e] = (float)(E[e] * inv);
+        ++ns;
+    }
+    return ns;
+}
+
+
+}  // namespace ph5

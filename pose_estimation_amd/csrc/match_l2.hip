@@ -119,52 +119,69 @@ __global__ __launch_bounds__(256, 2) void l2_top2_f32_kernel(
         if (tid < kTR) ((float*)tnl[buf])[tid] = stage_tn;
     };
 
+    // top-2 update of one 32x32 result tile: in-lane scan, increasing train row => strict '>' keeps
+    // the lowest index
+    auto scan = [&](const f32x16& acc, int ct, int t0) {
+        const int jb = t0 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            const int j = jb + (r & 3) + 8 * (r >> 2);
+            const bool gt = v > m1[ct];
+            m2[ct] = __builtin_amdgcn_fmed3f(m1[ct], m2[ct], v);
+            m1[ct] = gt ? v : m1[ct];
+            bi[ct] = gt ? j : bi[ct];
+        }
+    };
+
     if (t_begin < t_end) {
         fetch(t_begin);
         int cur = 0;
+        // Column tiles are processed one after the other (ct-major) and the scan of a finished tile
+        // is issued next to the MFMA chain of the following one, so the VALU epilogue overlaps
+        // matrix work inside one wave: scan(acc of ct=1, previous row tile) runs under the ct=0
+        // chain of the current row tile, scan(ct=0) under the ct=1 chain.
+        f32x16 acc1;
+        int t_prev = -1;
         for (int t0 = t_begin; t0 < t_end; t0 += kTR) {
             commit(cur);
             __syncthreads();
             if (t0 + kTR < t_end) fetch(t0 + kTR);
 
-            f32x16 acc[kQT];
+            const float4* trow = &tile[cur][li * CPR];
+            f32x16 acc0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 z = tnl[cur][2 * g + h];      // rows 8g + 4h .. +3
-#pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) {
-                    acc[ct][4 * g + 0] = z.x; acc[ct][4 * g + 1] = z.y;
-                    acc[ct][4 * g + 2] = z.z; acc[ct][4 * g + 3] = z.w;
-                }
+                acc0[4 * g + 0] = z.x; acc0[4 * g + 1] = z.y; acc0[4 * g + 2] = z.z; acc0[4 * g + 3] = z.w;
             }
-            const float4* trow = &tile[cur][li * CPR];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const float4 a = trow[(2 * c + h) ^ (li & 15)];
-#pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) {
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[ct][c].x, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[ct][c].y, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[ct][c].z, acc[ct], 0, 0, 0);
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[ct][c].w, acc[ct], 0, 0, 0);
-                }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[0][c].x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[0][c].y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[0][c].z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[0][c].w, acc0, 0, 0, 0);
             }
-            // fused top-2: in-lane scan, increasing train row => strict '>' keeps the lowest index
-            const int jb = t0 + 4 * h;
+            if (t_prev >= 0) scan(acc1, 1, t_prev);        // independent of the chain above
 #pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[ct][r];
-                    const int j = jb + (r & 3) + 8 * (r >> 2);
-                    const bool gt = v > m1[ct];
-                    m2[ct] = __builtin_amdgcn_fmed3f(m1[ct], m2[ct], v);
-                    m1[ct] = gt ? v : m1[ct];
-                    bi[ct] = gt ? j : bi[ct];
-                }
+            for (int g = 0; g < 4; ++g) {
+                const float4 z = tnl[cur][2 * g + h];
+                acc1[4 * g + 0] = z.x; acc1[4 * g + 1] = z.y; acc1[4 * g + 2] = z.z; acc1[4 * g + 3] = z.w;
             }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float4 a = trow[(2 * c + h) ^ (li & 15)];
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[1][c].x, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[1][c].y, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[1][c].z, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[1][c].w, acc1, 0, 0, 0);
+            }
+            scan(acc0, 0, t0);
+            t_prev = t0;
             cur ^= 1;
         }
+        scan(acc1, 1, t_prev);
     }
 
     // merge the two lane halves (same query, disjoint train rows)

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
                                                    const int32_t* __restrict__ n_valid, int H, int N, int psplits,
                                                    int pts_per_split, float thr_sq, int32_t* __restrict__ count) {
     constexpr int NP = Model::kParams, NA = Model::kArrays;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
     const int h0 = (blockIdx.x * 4 + wave) * kHPW;
     if (h0 >= H) return;                                   // wave-uniform; no barriers below
@@ -70,39 +71,44 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
     const int p_begin = blockIdx.y * pts_per_split;
     const int p_end = min(nv, p_begin + pts_per_split);
 
+    // the wave's hypotheses stay in registers for the whole kernel (tail waves re-score H-1)
+    float m[kHPW][NP];
+#pragma unroll
+    for (int k = 0; k < kHPW; ++k) {
+        const float* mb = models + ((size_t)b * H + min(h0 + k, H - 1)) * NP;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) {
+            m[k][e] = mb[e];
+            // pin the (wave-uniform) value in a VGPR: as SGPR operands the 72-96 model words overflow the
+            // scalar file and every fma with two of them needs a v_mov (one constant-bus read per VALU op)
+            asm volatile("" : "+v"(m[k][e]));
+        }
+    }
     int cnt[kHPW];
 #pragma unroll
     for (int k = 0; k < kHPW; ++k) cnt[k] = 0;
 
-    const float* mb = models + ((size_t)b * H + h0) * NP;
-    const int nh = min(kHPW, H - h0);
-
+    const size_t row = (size_t)b * N;
     for (int c0 = p_begin; c0 < p_end; c0 += 64 * kPPL) {
         float pt[kPPL][NA];
 #pragma unroll
         for (int p = 0; p < kPPL; ++p) {
             const int i = c0 + p * 64 + lane;
-            const bool ok = i < p_end;
+            const size_t o = row + min(i, p_end - 1);
 #pragma unroll
-            for (int a = 0; a < NA; ++a) pt[p][a] = ok ? pts.a[a][(size_t)b * N + i] : NAN;   // NaN never passes '<'
+            for (int a = 0; a < NA; ++a) pt[p][a] = pts.a[a][o];
+            pt[p][0] = (i < p_end) ? pt[p][0] : NAN;        // a NaN coordinate never passes '<'
         }
 #pragma unroll
         for (int k = 0; k < kHPW; ++k) {
-            if (k < nh) {
-                float m[NP];
 #pragma unroll
-                for (int e = 0; e < NP; ++e) m[e] = mb[k * NP + e];            // wave-uniform address
-                int c = 0;
-#pragma unroll
-                for (int p = 0; p < kPPL; ++p) c += __popcll(__ballot(Model::test(m, pt[p], thr_sq)));
-                cnt[k] += c;
-            }
+            for (int p = 0; p < kPPL; ++p) cnt[k] += __popcll(__ballot(Model::test(m[k], pt[p], thr_sq)));
         }
     }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < kHPW; ++k) {
-            if (k < nh) {
+            if (h0 + k < H) {
                 int32_t* dst = count + (size_t)b * H + h0 + k;
                 if (psplits == 1) *dst = cnt[k]; else atomicAdd(dst, cnt[k]);
             }

@@ -26,6 +26,34 @@ def _models(m, B, width, name):
     return m
 
 
+def sample_minimal(seed, n_valid, N, n_samples, m=5):
+    """Counter-based (Philox4x32-10) minimal samples: int32 ``[B, n_samples, m]`` distinct indices per row."""
+    lib = L.load()
+    n_valid = L.dev(n_valid, torch.int32, "n_valid")
+    B = n_valid.numel()
+    out = torch.empty((B, n_samples, m), dtype=torch.int32, device=n_valid.device)
+    L.check(lib.ph_sample_minimal(int(seed) & 0xFFFFFFFF, L.ptr(n_valid), B, int(N), int(n_samples), int(m), L.ptr(out),
+                                  L.stream_ptr()), "ph_sample_minimal")
+    return out
+
+
+def solve_essential_5pt(x1, y1, x2, y2, samples, want_counts=False):
+    """Nister 5-point solver on the device.  samples int32 ``[B, S, 5]`` -> E ``[B, 10*S, 9]`` float32
+    (10 slots per sample, unused slots zero) and optionally the per-sample solution counts ``[B, S]``."""
+    lib = L.load()
+    x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
+    B, N = x1.shape
+    samples = L.dev(samples, torch.int32, "samples")
+    if samples.dim() != 3 or samples.shape[0] != B or samples.shape[2] != 5:
+        raise ValueError("samples must be [B, S, 5]")
+    S = samples.shape[1]
+    E = torch.empty((B, 10 * S, 9), dtype=torch.float32, device=x1.device)
+    ns = torch.empty((B, S), dtype=torch.int32, device=x1.device) if want_counts else None
+    L.check(lib.ph_solve_essential_5pt(L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(samples), B, S, N, L.ptr(E),
+                                       L.ptr(ns), L.stream_ptr()), "ph_solve_essential_5pt")
+    return (E, ns) if want_counts else E
+
+
 def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None):
     """Inlier count of every E hypothesis (Sampson error < thr).  Returns int32 ``[B, H]``."""
     lib = L.load()
