@@ -5,8 +5,8 @@ Workload (BASELINE.json configs[1]): synthetic two-view pairs, 8192 SIFT-style f
 descriptors (dim 128) per view, 4096 RANSAC essential-matrix hypotheses per pair.  One step =
 one pass of the hot path over a batch of --pairs such pairs per GPU, inputs resident in HBM:
 
-    row norms -> L2 top-2 (fp32 MFMA) -> ratio test -> compaction -> Sampson scoring of H
-    hypotheses -> best -> inlier mask -> [host: 3x3 SVD decomposition] -> 4-candidate
+    row norms -> L2 top-2 (fp32 MFMA) -> ratio test -> compaction -> Philox minimal samples ->
+    5-point solver (hypothesis generation) -> Sampson scoring of H hypotheses -> best -> inlier mask -> [host: 3x3 SVD decomposition] -> 4-candidate
     triangulation + cheirality vote -> pose table  (-> all_gather of the table when N > 1)
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
@@ -27,38 +27,32 @@ sys.path.insert(0, ROOT)
 from pose_estimation_amd import matching, pipeline, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-N_FEAT, DIM, N_HYP = 8192, 128, 4096
+N_FEAT, DIM = 8192, 128
+N_SAMPLES = 410                 # minimal samples per pair; the 5-point solver fills 10 hypothesis slots each
+N_HYP = 10 * N_SAMPLES          # 4100 essential-matrix hypotheses scored per pair (>= the 4096 of configs[1])
 THR_PX = 1.0
 
 
-def make_hypotheses(rng, R, t, H):
-    """H essential-matrix hypotheses for one pair: a few near the truth, the rest perturbed."""
-    E = np.empty((H, 9), np.float32)
-    for h in range(H):
-        s = 0.0 if h == H // 3 else (0.002 if h % 16 == 0 else 0.05)
-        w = rng.normal(0, s, 3)
-        E[h] = synthetic.essential_from_pose((np.eye(3) + synthetic.skew(w)) @ R, t + rng.normal(0, 2 * s, 3)).reshape(9)
-    return E
-
-
 def make_batch(pairs, rank, dev):
-    d1, d2, k1, k2, E, truth = [], [], [], [], [], []
+    d1, d2, k1, k2, truth = [], [], [], [], []
     for p in range(pairs):
         sc = synthetic.two_view_pair(n=N_FEAT, dim=DIM, seed=1002 + 7919 * rank + p)
         d1.append(sc["desc1"]); d2.append(sc["desc2"]); k1.append(sc["kp1"]); k2.append(sc["kp2"])
-        E.append(make_hypotheses(np.random.default_rng(p + 31 * rank), sc["R"], sc["t"], N_HYP))
         truth.append((sc["R"], sc["t"]))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev)
-    return dict(desc_q=t(d1), desc_t=t(d2), kp_q=t(k1), kp_t=t(k2), E=t(E), truth=truth,
-                host=dict(desc_q=d1, desc_t=d2, kp_q=k1, kp_t=k2, E=E))
+    return dict(desc_q=t(d1), desc_t=t(d2), kp_q=t(k1), kp_t=t(k2), truth=truth,
+                host=dict(desc_q=d1, desc_t=d2, kp_q=k1, kp_t=k2))
 
 
-def cpu_baseline(batch, n_pairs, threads):
-    """The CPU oracle ('port') over the same stages on a bounded sample of the same workload."""
+def cpu_baseline(batch, n_pairs, threads, E_dev):
+    """The CPU oracle ('port') over the same stages on a bounded sample of the same workload.
+
+    Hypothesis generation is NOT part of the CPU leg (the oracle's 5-point solver is NumPy and would
+    dominate it): the CPU scores the hypotheses the GPU generated, which only flatters the CPU."""
     from oracle import oracle as orc
     orc.set_num_threads(threads)
     thr_sq = np.float32((THR_PX / synthetic.FX) ** 2)
-    h = batch["host"]
+    h = dict(batch["host"], E=E_dev.cpu().numpy())
     t0 = time.perf_counter()
     for p in range(n_pairs):
         idx, a, b = orc.match_l2_top2(h["desc_q"][p], h["desc_t"][p])
@@ -75,7 +69,7 @@ def cpu_baseline(batch, n_pairs, threads):
             orc.triangulate(P1[0, c], P2[0, c], *pts, mask)
     dt = time.perf_counter() - t0
     return {"value": n_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{n_pairs} pair(s) of the same workload through oracle/posehot_oracle.c (OpenMP, {threads} threads), {dt:.1f} s"}
+            "sample": f"{n_pairs} pair(s) of the same workload through oracle/posehot_oracle.c (OpenMP, {threads} threads), hypothesis generation excluded, {dt:.1f} s"}
 
 
 def main():
@@ -120,7 +114,8 @@ def main():
         return (*r, "l2")
 
     def step():
-        out = pipeline.relative_pose_batch(match, batch["kp_q"], batch["kp_t"], None, None, batch["E"], thr_sq)
+        out = pipeline.relative_pose_batch(match, batch["kp_q"], batch["kp_t"], None, None, None, thr_sq,
+                                           n_samples=N_SAMPLES, seed=state["step"] + 1000)
         if world > 1:
             dist.all_gather_into_tensor(gathered, out["table"])
         return out
@@ -167,7 +162,8 @@ def main():
             "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
                                    "4096 essential-matrix hypotheses per pair", "pairs_per_step_per_gpu": P,
                        "features": N_FEAT, "dim": DIM, "hypotheses": N_HYP, "ratio": 0.75, "threshold_px": THR_PX,
-                       "hypothesis_source": "resident in HBM (pre-generated around ground truth; minimal solver not in the timed region)",
+                       "minimal_samples": N_SAMPLES,
+                       "hypothesis_source": "generated in the timed region: Philox minimal samples of the pair's own matches -> device 5-point solver (10 slots per sample)",
                        "parallelism": f"pairs sharded over {world} rank(s), final all_gather of the [pairs,16] pose table"},
             "hyps_per_sec": world * P * N_HYP * args.steps / dt,
             "roofline": {"kernel": "l2_top2_f32_kernel<128>", "bound": "mfma", "achieved": achieved,
@@ -177,7 +173,7 @@ def main():
         }
         if world == 1 and args.cpu_pairs > 0:
             threads = min(16, os.cpu_count() or 1)
-            res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads)
+            res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads, out["E_hyp"])
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

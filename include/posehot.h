@@ -124,14 +124,17 @@ int ph_compact_matches(const int32_t* idx, const int32_t* keep,
 int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, int N, int S, int m,
                       int32_t* samples, void* stream);
 
-/* Nister 5-point essential-matrix solver, one minimal sample per thread (float64 inside).
- * samples is [B][S][5] (indices into the item's N correspondences, normalised coordinates).
- * E is [B][S*10][9] f32: sample s owns hypothesis slots 10s .. 10s+9; each real solution is a
- * unit-Frobenius-norm E, unused slots are all-zero (they score zero inliers).  n_solutions
- * ([B][S], may be NULL) = number of real solutions of each sample.  SURVEY.md §8f item 1. */
+/* Nister 5-point essential-matrix solver (float64 inside).  Two launches: one thread per minimal
+ * sample builds the degree-10 polynomial, then one lane per (sample, root) runs the Aberth-Ehrlich
+ * root iteration and turns its root into an E.  samples is [B][S][5] (indices into the item's N
+ * correspondences, normalised coordinates).  E is [B][S*10][9] f32: sample s owns hypothesis
+ * slots 10s .. 10s+9 (slot = root index); a real root gives a unit-Frobenius-norm E, every other
+ * slot is all-zero (it scores zero inliers).  n_solutions ([B][S], may be NULL) = real solutions
+ * per sample.  ws: ph_solve_essential_5pt_ws_bytes(B, S) bytes.  SURVEY.md §8f item 1. */
+size_t ph_solve_essential_5pt_ws_bytes(int B, int S);
 int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
                            const int32_t* samples, int B, int S, int N,
-                           float* E, int32_t* n_solutions, void* stream);
+                           float* E, int32_t* n_solutions, void* ws, size_t ws_bytes, void* stream);
 
 /* Sampson distance of (x1,y1)->(x2,y2) (normalised image coordinates) under E (row-major 9):
  * inlier iff (x2' E x1)^2 < thr_sq * ((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2). */

@@ -44,7 +44,8 @@ SIGNATURES = {
     "ph_ratio_filter_l2": (_i, [_p, _p, _p, _i64, _f, _p, _p]),
     "ph_compact_matches": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ph_sample_minimal": (_i, [C.c_uint32, _p, _i, _i, _i, _i, _p, _p]),
-    "ph_solve_essential_5pt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "ph_solve_essential_5pt_ws_bytes": (_sz, [_i, _i]),
+    "ph_solve_essential_5pt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "ph_score_essential": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p]),
     "ph_score_pnp": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p]),
     "ph_select_best": (_i, [_p, _i, _i, _p, _p, _p]),

@@ -55,27 +55,84 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const int32_
     for (int k = 0; k < m; ++k) o[k] = got[k];
 }
 
-__global__ __launch_bounds__(64) void fivepoint_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
-                                                      const float* __restrict__ x2, const float* __restrict__ y2,
-                                                      const int32_t* __restrict__ samples, int S, int N,
-                                                      float* __restrict__ E_out, int32_t* __restrict__ n_sol) {
+// Stage 1: one thread per minimal sample builds the degree-10 polynomial (sections 1-8 of the core).
+__global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+                                                           const float* __restrict__ x2, const float* __restrict__ y2,
+                                                           const int32_t* __restrict__ samples, int S, int N,
+                                                           ph5::Poly5* __restrict__ polys) {
     const int b = blockIdx.y;
     const int s = blockIdx.x * 64 + threadIdx.x;
     if (s >= S) return;
-    float* eo = E_out + ((size_t)b * S + s) * 90;
-    for (int k = 0; k < 90; ++k) eo[k] = 0.0f;
-    if (n_sol) n_sol[(size_t)b * S + s] = 0;
+    ph5::Poly5* out = polys + (size_t)b * S + s;
     const int32_t* si = samples + ((size_t)b * S + s) * 5;
-
     double pts[5][4];
+    bool ok = true;
     for (int r = 0; r < 5; ++r) {
         const int i = si[r];
-        if (i < 0 || i >= N) return;
-        const size_t o = (size_t)b * N + i;
+        ok &= (i >= 0 && i < N);
+        const size_t o = (size_t)b * N + (ok ? i : 0);
         pts[r][0] = x1[o]; pts[r][1] = y1[o]; pts[r][2] = x2[o]; pts[r][3] = y2[o];
     }
-    const int ns = ph5::solve_fivepoint(pts, eo);
-    if (n_sol) n_sol[(size_t)b * S + s] = ns;
+    ph5::Poly5 P;
+    if (!ok || !ph5::build_polynomial(pts, P)) P.n = 0;
+    *out = P;
+}
+
+// Stage 2: one lane per (sample, root): 6 samples x 10 roots per wave (lanes 60-63 idle).  The ten lanes
+// of a sample run the Aberth-Ehrlich iteration together (simultaneous update, roots exchanged by
+// shuffles), then every lane turns its own root into an essential matrix and writes slot k.
+__global__ __launch_bounds__(64) void fivepoint_roots_kernel(const ph5::Poly5* __restrict__ polys, long n_samples,
+                                                            float* __restrict__ E_out, int32_t* __restrict__ n_sol) {
+    const int lane = threadIdx.x;
+    const int g = lane / 10, k = lane - 10 * g;
+    const long s = (long)blockIdx.x * 6 + g;
+    const bool active = (g < 6) && (s < n_samples);
+    const ph5::Poly5* Pp = polys + (active ? s : 0);
+    ph5::Poly5 P;
+    for (int q = 0; q < 11; ++q) P.c[q] = Pp->c[q];
+    P.n = Pp->n;
+    const int n = P.n;
+    const bool live = active && k < n;
+    ph5::cplx z = live ? ph5::aberth_start(P, k) : ph5::cplx{0.0, 0.0};
+    for (int it = 0; it < 100; ++it) {
+        ph5::cplx sum = {0.0, 0.0};
+        for (int d = 1; d < 10; ++d) {
+            int kk = k + d; kk = kk >= 10 ? kk - 10 : kk;
+            const int src = min(10 * g + kk, 63);
+            const double zr = __shfl(z.re, src), zi = __shfl(z.im, src);
+            if (kk < n) {
+                const ph5::cplx dd = {z.re - zr, z.im - zi};
+                const ph5::cplx inv = ph5::cdiv(ph5::cplx{1.0, 0.0}, dd);
+                sum.re += inv.re; sum.im += inv.im;
+            }
+        }
+        double change = 0.0;
+        if (live) {
+            const ph5::cplx w = ph5::aberth_step(P, z, sum);
+            z.re -= w.re; z.im -= w.im;
+            change = (fabs(w.re) + fabs(w.im)) / (fabs(z.re) + fabs(z.im) + 1e-30);
+        }
+        if (__all(change < 1e-15)) break;                // wave-uniform exit
+    }
+    float e9[9];
+    bool real = false;
+    if (live) {
+        for (int q = 0; q < 3; ++q) {
+            for (int r = 0; r < 4; ++r) { P.Bx[q][r] = Pp->Bx[q][r]; P.By[q][r] = Pp->By[q][r]; }
+            for (int r = 0; r < 5; ++r) P.B1[q][r] = Pp->B1[q][r];
+        }
+        for (int q = 0; q < 4; ++q)
+            for (int r = 0; r < 9; ++r) P.basis[q][r] = Pp->basis[q][r];
+        real = ph5::root_to_E(P, z, e9);
+    }
+    if (active) {
+        float* eo = E_out + (size_t)s * 90 + 9 * k;
+        for (int e = 0; e < 9; ++e) eo[e] = real ? e9[e] : 0.0f;
+    }
+    if (n_sol) {
+        const unsigned long long votes = __ballot(real);
+        if (active && k == 0) n_sol[s] = (int32_t)__popcll((votes >> (10 * g)) & 0x3ffull);
+    }
 }
 
 }  // namespace
@@ -91,14 +148,25 @@ extern "C" int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, i
     return ph_launch_status();
 }
 
+extern "C" size_t ph_solve_essential_5pt_ws_bytes(int B, int S) {
+    if (B <= 0 || S <= 0) return 0;
+    return sizeof(ph5::Poly5) * (size_t)B * S;
+}
+
 extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
                                       const int32_t* samples, int B, int S, int N, float* E, int32_t* n_solutions,
-                                      void* stream) {
+                                      void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || S < 0 || N < 0) return PH_ERR_INVALID_ARG;
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || S == 0) return PH_OK;
     if (!x1 || !y1 || !x2 || !y2 || !samples || !E) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(fivepoint_kernel, dim3(ph_ceil_div(S, 64), B), dim3(64), 0, (hipStream_t)stream, x1, y1, x2, y2,
-                       samples, S, N, E, n_solutions);
+    if (!ws || ws_bytes < ph_solve_essential_5pt_ws_bytes(B, S) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    ph5::Poly5* polys = (ph5::Poly5*)ws;
+    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3(ph_ceil_div(S, 64), B), dim3(64), 0, st, x1, y1, x2, y2, samples, S, N,
+                       polys);
+    const long n_samples = (long)B * S;
+    hipLaunchKernelGGL(fivepoint_roots_kernel, dim3((unsigned)((n_samples + 5) / 6)), dim3(64), 0, st, polys, n_samples, E,
+                       n_solutions);
     return ph_launch_status();
 }

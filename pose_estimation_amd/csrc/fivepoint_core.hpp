@@ -44,7 +44,22 @@ PH_HD inline cplx cdiv(cplx a, cplx b) {
 
 // pts[r] = (x1, y1, x2, y2) of correspondence r; eo = 90 floats (10 slots), pre-zeroed by the caller.
 // Returns the number of real solutions written.
-PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
+// Everything the root stage needs about one minimal sample.
+struct Poly5 {
+    double c[11];                        // det B(z), ascending powers; degree n
+    double Bx[3][4], By[3][4], B1[3][5]; // rows k, l, m of B(z): x, y and constant parts
+    double basis[4][9];                  // null-space basis X, Y, Z, W (E = xX + yY + zZ + W)
+    int n;                               // polynomial degree, 0 = degenerate sample (no solutions)
+};
+
+// Sections 1-8: minimal sample -> polynomial.  pts[r] = (x1, y1, x2, y2).
+PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P) {
+    P.n = 0;
+    double (&basis)[4][9] = P.basis;
+    double (&Bx)[3][4] = P.Bx;
+    double (&By)[3][4] = P.By;
+    double (&B1)[3][5] = P.B1;
+    double (&c)[11] = P.c;
     // ---- 1. epipolar rows q . vec(E) = x2' E x1
     double Q[5][9];
     for (int r = 0; r < 5; ++r) {
@@ -60,7 +75,7 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
         double best = -1.0;
         for (int i = r; i < 5; ++i)
             for (int j = r; j < 9; ++j) { const double v = fabs(Q[i][perm[j]]); if (v > best) { best = v; pi = i; pj = j; } }
-        if (!(best > 1e-12)) return 0;                                   // degenerate sample
+        if (!(best > 1e-12)) return false;                                   // degenerate sample
         if (pi != r) for (int j = 0; j < 9; ++j) { const double t = Q[r][j]; Q[r][j] = Q[pi][j]; Q[pi][j] = t; }
         { const int t = perm[r]; perm[r] = perm[pj]; perm[pj] = t; }
         const double inv = 1.0 / Q[r][perm[r]];
@@ -71,7 +86,6 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
             for (int j = 0; j < 9; ++j) Q[i][j] -= f * Q[r][j];
         }
     }
-    double basis[4][9];
     for (int k = 0; k < 4; ++k) {
         for (int j = 0; j < 9; ++j) basis[k][j] = 0.0;
         basis[k][perm[5 + k]] = 1.0;
@@ -131,7 +145,7 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
         int p = c;
         double best = fabs(A[c][c]);
         for (int i = c + 1; i < 10; ++i) { const double v = fabs(A[i][c]); if (v > best) { best = v; p = i; } }
-        if (!(best > 1e-14)) return 0;
+        if (!(best > 1e-14)) return false;
         if (p != c) for (int j = 0; j < 20; ++j) { const double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
         const double inv = 1.0 / A[c][c];
         for (int j = c; j < 20; ++j) A[c][j] *= inv;
@@ -142,7 +156,6 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
         }
     }
     // ---- 7. k = e - z f, l = g - z h, m = i - z j  (ascending powers of z; x, y parts degree 3, 1 part degree 4)
-    double Bx[3][4], By[3][4], B1[3][5];
     for (int q = 0; q < 3; ++q) {
         const double* p = &A[4 + 2 * q][10];
         const double* r = &A[5 + 2 * q][10];
@@ -151,7 +164,6 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
         B1[q][4] = -r[6]; B1[q][3] = p[6] - r[7]; B1[q][2] = p[7] - r[8]; B1[q][1] = p[8] - r[9]; B1[q][0] = p[9];
     }
     // ---- 8. det B(z), degree 10
-    double c[11];
     for (int k = 0; k < 11; ++k) c[k] = 0.0;
     {
         double t7[8], t6[7];
@@ -165,33 +177,95 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
         pmul_acc(Bx[1], 4, By[2], 4, 1.0, t6); pmul_acc(By[1], 4, Bx[2], 4, -1.0, t6);
         pmul_acc(B1[0], 5, t6, 7, 1.0, c);
     }
-    // ---- 9. all roots by Aberth-Ehrlich
     int n = 10;
     double cmax = 0.0;
     for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(c[k]));
-    if (!(cmax > 0.0) || !(cmax < HUGE_VAL)) return 0;
-    while (n > 0 && fabs(c[n]) <= 1e-30 * cmax) --n;
-    if (n < 1) return 0;
-    cplx z[10];
-    {
-        double rad = pow(fabs(c[0] / c[n]) + 1e-300, 1.0 / n);
-        rad = fmin(fmax(rad, 1e-3), 1e3);
-        for (int k = 0; k < n; ++k) {
-            double sn, cs;
-            sn = sin(6.283185307179586 * k / n + 0.4); cs = cos(6.283185307179586 * k / n + 0.4);
-            z[k] = {rad * cs, rad * sn};
-        }
+    if (!(cmax > 0.0) || !(cmax < HUGE_VAL)) return false;
+    while (n > 0 && fabs(c[n]) <= 1e-30 * cmax) --n;   // a tiny leading coefficient is a legitimate huge root: keep it
+    if (n < 1) return false;
+    P.n = n;
+    return true;
+}
+
+// Aberth-Ehrlich start values: n points on a circle of the geometric-mean root radius.
+PH_HD inline cplx aberth_start(const Poly5& P, int k) {
+    double rad = pow(fabs(P.c[0] / P.c[P.n]) + 1e-300, 1.0 / P.n);
+    rad = fmin(fmax(rad, 1e-3), 1e3);
+    const double a = 6.283185307179586 * k / P.n + 0.4;
+    return {rad * cos(a), rad * sin(a)};
+}
+
+// One Aberth correction for root zk given sum_j 1/(zk - zj) over the other roots; returns the step w (z -= w).
+PH_HD inline cplx aberth_step(const Poly5& P, cplx zk, cplx sum) {
+    const int n = P.n;
+    cplx p = {P.c[n], 0.0}, dp = {0.0, 0.0};
+    for (int j = n - 1; j >= 0; --j) {
+        dp = cmul(dp, zk); dp.re += p.re; dp.im += p.im;
+        p = cmul(p, zk); p.re += P.c[j];
     }
+    if (p.re == 0.0 && p.im == 0.0) return {0.0, 0.0};
+    const cplx nw = cdiv(p, dp);                          // Newton step
+    const cplx den = {1.0 - (nw.re * sum.re - nw.im * sum.im), -(nw.re * sum.im + nw.im * sum.re)};
+    const cplx w = cdiv(nw, den);
+    if (w.re == w.re && w.im == w.im) return w;
+    return {0.0, 0.0};
+}
+
+// A converged root -> the essential matrix it defines (unit Frobenius norm, f32); false when the root is not real.
+PH_HD inline bool root_to_E(const Poly5& P, cplx z, float* e9) {
+    const int n = P.n;
+    if (!(fabs(z.im) < 1e-6 * fmax(1.0, fabs(z.re)))) return false;
+    double zr = z.re;
+    for (int it = 0; it < 6; ++it) {                       // polish on the real axis
+        double p = P.c[n], dp = 0.0;
+        for (int j = n - 1; j >= 0; --j) { dp = dp * zr + p; p = p * zr + P.c[j]; }
+        if (dp != 0.0) zr -= p / dp;
+    }
+    {   // a complex pair with a tiny imaginary part is not a solution: require p(zr) = 0 to rounding
+        double p = P.c[n], mag = fabs(P.c[n]);
+        const double az = fabs(zr);
+        for (int j = n - 1; j >= 0; --j) { p = p * zr + P.c[j]; mag = mag * az + fabs(P.c[j]); }
+        if (!(fabs(p) <= 1e-10 * mag)) return false;
+    }
+    double Bz[3][3];
+    for (int q = 0; q < 3; ++q) {
+        Bz[q][0] = ((P.Bx[q][3] * zr + P.Bx[q][2]) * zr + P.Bx[q][1]) * zr + P.Bx[q][0];
+        Bz[q][1] = ((P.By[q][3] * zr + P.By[q][2]) * zr + P.By[q][1]) * zr + P.By[q][0];
+        Bz[q][2] = (((P.B1[q][4] * zr + P.B1[q][3]) * zr + P.B1[q][2]) * zr + P.B1[q][1]) * zr + P.B1[q][0];
+    }
+    double v[3] = {0, 0, 0}, vbest = -1.0;                 // null vector = largest cross product of two rows
+    for (int q = 0; q < 3; ++q) {
+        const double* a = Bz[q];
+        const double* d = Bz[(q + 1) % 3];
+        const double w0 = a[1] * d[2] - a[2] * d[1], w1 = a[2] * d[0] - a[0] * d[2], w2 = a[0] * d[1] - a[1] * d[0];
+        const double nn = w0 * w0 + w1 * w1 + w2 * w2;
+        if (nn > vbest) { vbest = nn; v[0] = w0; v[1] = w1; v[2] = w2; }
+    }
+    if (!(fabs(v[2]) > 1e-14 * sqrt(vbest))) return false;
+    const double xr = v[0] / v[2], yr = v[1] / v[2];
+    double E[9], n2 = 0.0;
+    for (int e = 0; e < 9; ++e) {
+        E[e] = xr * P.basis[0][e] + yr * P.basis[1][e] + zr * P.basis[2][e] + P.basis[3][e];
+        n2 += E[e] * E[e];
+    }
+    if (!(n2 > 0.0) || !(n2 < HUGE_VAL)) return false;
+    const double inv = 1.0 / sqrt(n2);
+    for (int e = 0; e < 9; ++e) e9[e] = (float)(E[e] * inv);
+    return true;
+}
+
+// Sequential reference of the whole solver (host debug harness; the device splits it over two kernels).
+// eo = 90 floats (10 slots, slot k = root k), pre-zeroed by the caller.  Returns the number of real solutions.
+PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
+    Poly5 P;
+    if (!build_polynomial(pts, P)) return 0;
+    const int n = P.n;
+    cplx z[10];
+    for (int k = 0; k < n; ++k) z[k] = aberth_start(P, k);
     for (int it = 0; it < 100; ++it) {
+        cplx w[10];
         double worst = 0.0;
         for (int k = 0; k < n; ++k) {
-            cplx p = {c[n], 0.0}, dp = {0.0, 0.0};
-            for (int j = n - 1; j >= 0; --j) {
-                dp = cmul(dp, z[k]); dp.re += p.re; dp.im += p.im;
-                p = cmul(p, z[k]); p.re += c[j];
-            }
-            if (p.re == 0.0 && p.im == 0.0) continue;
-            const cplx nw = cdiv(p, dp);                      // Newton step
             cplx sum = {0.0, 0.0};
             for (int j = 0; j < n; ++j) {
                 if (j == k) continue;
@@ -199,63 +273,17 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
                 const cplx inv = cdiv(cplx{1.0, 0.0}, d);
                 sum.re += inv.re; sum.im += inv.im;
             }
-            const cplx den = {1.0 - (nw.re * sum.re - nw.im * sum.im), -(nw.re * sum.im + nw.im * sum.re)};
-            const cplx w = cdiv(nw, den);
-            if (w.re == w.re && w.im == w.im) {
-                z[k].re -= w.re; z[k].im -= w.im;
-                worst = fmax(worst, (fabs(w.re) + fabs(w.im)) / (fabs(z[k].re) + fabs(z[k].im) + 1e-30));
-            }
+            w[k] = aberth_step(P, z[k], sum);
+        }
+        for (int k = 0; k < n; ++k) {                     // simultaneous (Jacobi) update, as the device does
+            z[k].re -= w[k].re; z[k].im -= w[k].im;
+            worst = fmax(worst, (fabs(w[k].re) + fabs(w[k].im)) / (fabs(z[k].re) + fabs(z[k].im) + 1e-30));
         }
         if (worst < 1e-15) break;
     }
-#ifdef PH5_DEBUG
-    printf("n=%d coeffs:", n); for (int k = 0; k <= n; ++k) printf(" %.17g", c[k]); printf("\nroots:");
-    for (int k = 0; k < n; ++k) printf(" (%.12g,%.3g)", z[k].re, z[k].im); printf("\n");
-#endif
-    // ---- 10. real roots -> (x, y) from the null vector of B(z) -> E
     int ns = 0;
-    for (int k = 0; k < n && ns < 10; ++k) {
-        if (!(fabs(z[k].im) < 1e-6 * fmax(1.0, fabs(z[k].re)))) continue;
-        double zr = z[k].re;
-        for (int it = 0; it < 6; ++it) {                       // polish on the real axis
-            double p = c[n], dp = 0.0;
-            for (int j = n - 1; j >= 0; --j) { dp = dp * zr + p; p = p * zr + c[j]; }
-            if (dp != 0.0) zr -= p / dp;
-        }
-        {   // a complex pair with a tiny imaginary part is not a solution: require p(zr) = 0 to rounding
-            double p = c[n], mag = fabs(c[n]);
-            const double az = fabs(zr);
-            for (int j = n - 1; j >= 0; --j) { p = p * zr + c[j]; mag = mag * az + fabs(c[j]); }
-            if (!(fabs(p) <= 1e-10 * mag)) continue;
-        }
-        double Bz[3][3];
-        for (int q = 0; q < 3; ++q) {
-            Bz[q][0] = ((Bx[q][3] * zr + Bx[q][2]) * zr + Bx[q][1]) * zr + Bx[q][0];
-            Bz[q][1] = ((By[q][3] * zr + By[q][2]) * zr + By[q][1]) * zr + By[q][0];
-            Bz[q][2] = (((B1[q][4] * zr + B1[q][3]) * zr + B1[q][2]) * zr + B1[q][1]) * zr + B1[q][0];
-        }
-        double v[3] = {0, 0, 0}, vbest = -1.0;                 // null vector = largest cross product of two rows
-        for (int q = 0; q < 3; ++q) {
-            const double* a = Bz[q];
-            const double* d = Bz[(q + 1) % 3];
-            const double w0 = a[1] * d[2] - a[2] * d[1], w1 = a[2] * d[0] - a[0] * d[2], w2 = a[0] * d[1] - a[1] * d[0];
-            const double nn = w0 * w0 + w1 * w1 + w2 * w2;
-            if (nn > vbest) { vbest = nn; v[0] = w0; v[1] = w1; v[2] = w2; }
-        }
-        if (!(fabs(v[2]) > 1e-14 * sqrt(vbest))) continue;
-        const double xr = v[0] / v[2], yr = v[1] / v[2];
-        double E[9], n2 = 0.0;
-        for (int e = 0; e < 9; ++e) {
-            E[e] = xr * basis[0][e] + yr * basis[1][e] + zr * basis[2][e] + basis[3][e];
-            n2 += E[e] * E[e];
-        }
-        if (!(n2 > 0.0) || !(n2 < HUGE_VAL)) continue;
-        const double inv = 1.0 / sqrt(n2);
-        for (int e = 0; e < 9; ++e) eo[9 * ns + e] = (float)(E[e] * inv);
-        ++ns;
-    }
+    for (int k = 0; k < n; ++k) ns += root_to_E(P, z[k], eo + 9 * k) ? 1 : 0;
     return ns;
 }
-
 
 }  // namespace ph5
