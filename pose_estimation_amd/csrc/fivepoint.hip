@@ -56,17 +56,24 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const int32_
 }
 
 // Stage 1: one thread per minimal sample builds the degree-10 polynomial (sections 1-8 of the core).
-__global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
-                                                           const float* __restrict__ x2, const float* __restrict__ y2,
-                                                           const int32_t* __restrict__ samples, int S, int N,
-                                                           ph5::Poly5* __restrict__ polys) {
+// Blocks are 32 threads wide on purpose: the work is a long dependent chain per sample over ~3.3 KB of
+// dynamically indexed working arrays, kept in LDS (32 x 3336 B per block), and with only B*S samples
+// the launch is latency-bound — more, narrower blocks spread the samples over all CUs.
+constexpr int kPolyThreads = 32;
+__global__ __launch_bounds__(kPolyThreads) void fivepoint_poly_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+                                                                     const float* __restrict__ x2, const float* __restrict__ y2,
+                                                                     const int32_t* __restrict__ samples, int S, int N,
+                                                                     ph5::Poly5* __restrict__ polys) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ph5::Work5* work = reinterpret_cast<ph5::Work5*>(smem);
     const int b = blockIdx.y;
-    const int s = blockIdx.x * 64 + threadIdx.x;
+    const int s = blockIdx.x * kPolyThreads + threadIdx.x;
     if (s >= S) return;
     ph5::Poly5* out = polys + (size_t)b * S + s;
     const int32_t* si = samples + ((size_t)b * S + s) * 5;
     double pts[5][4];
     bool ok = true;
+#pragma unroll
     for (int r = 0; r < 5; ++r) {
         const int i = si[r];
         ok &= (i >= 0 && i < N);
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
         pts[r][0] = x1[o]; pts[r][1] = y1[o]; pts[r][2] = x2[o]; pts[r][3] = y2[o];
     }
     ph5::Poly5 P;
-    if (!ok || !ph5::build_polynomial(pts, P)) P.n = 0;
+    if (!ok || !ph5::build_polynomial(pts, P, work[threadIdx.x])) P.n = 0;
     *out = P;
 }
 
@@ -163,8 +170,12 @@ extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const fl
     if (!ws || ws_bytes < ph_solve_essential_5pt_ws_bytes(B, S) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     ph5::Poly5* polys = (ph5::Poly5*)ws;
-    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3(ph_ceil_div(S, 64), B), dim3(64), 0, st, x1, y1, x2, y2, samples, S, N,
-                       polys);
+    const size_t lds = sizeof(ph5::Work5) * kPolyThreads;      // 106,752 B: above the 64 KiB default, opt in
+    if (hipFuncSetAttribute((const void*)fivepoint_poly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+        return PH_ERR_LAUNCH;
+    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3(ph_ceil_div(S, kPolyThreads), B), dim3(kPolyThreads), lds, st, x1, y1, x2,
+                       y2, samples, S, N, polys);
     const long n_samples = (long)B * S;
     hipLaunchKernelGGL(fivepoint_roots_kernel, dim3((unsigned)((n_samples + 5) / 6)), dim3(64), 0, st, polys, n_samples, E,
                        n_solutions);

@@ -52,8 +52,32 @@ struct Poly5 {
     int n;                               // polynomial degree, 0 = degenerate sample (no solutions)
 };
 
+// Working arrays of the polynomial stage.  They are indexed dynamically (pivoting), so on the device they
+// would live in private memory (HBM-backed); the kernel puts one Work5 per thread in LDS instead.
+// sizeof(Work5) = 8 * 417 bytes: an odd number of 8-byte words, so that the lanes of a wave touching the
+// same field hit distinct LDS banks.
+struct Work5 {
+    double Q[5][9];
+    double Ep[9][4];
+    double EEt[3][3][10];
+    double tr[10];
+    double A[10][20];
+    double tmp[20], d2[10];
+    int perm[10];
+    double pad;
+};
+static_assert(sizeof(Work5) == 8 * 417, "Work5 must be an odd number of 8-byte words");
+
 // Sections 1-8: minimal sample -> polynomial.  pts[r] = (x1, y1, x2, y2).
-PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P) {
+PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P, Work5& w) {
+    double (&Q)[5][9] = w.Q;
+    int (&perm)[10] = w.perm;
+    double (&Ep)[9][4] = w.Ep;
+    double (&EEt)[3][3][10] = w.EEt;
+    double (&tr)[10] = w.tr;
+    double (&A)[10][20] = w.A;
+    double (&tmp)[20] = w.tmp;
+    double (&d2)[10] = w.d2;
     P.n = 0;
     double (&basis)[4][9] = P.basis;
     double (&Bx)[3][4] = P.Bx;
@@ -61,14 +85,12 @@ PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P) {
     double (&B1)[3][5] = P.B1;
     double (&c)[11] = P.c;
     // ---- 1. epipolar rows q . vec(E) = x2' E x1
-    double Q[5][9];
     for (int r = 0; r < 5; ++r) {
         const double a = pts[r][0], c = pts[r][1], d = pts[r][2], e = pts[r][3];
         Q[r][0] = d * a; Q[r][1] = d * c; Q[r][2] = d; Q[r][3] = e * a; Q[r][4] = e * c; Q[r][5] = e;
         Q[r][6] = a; Q[r][7] = c; Q[r][8] = 1.0;
     }
     // ---- 2. null space: Gauss-Jordan with full pivoting, then modified Gram-Schmidt
-    int perm[9];
     for (int j = 0; j < 9; ++j) perm[j] = j;
     for (int r = 0; r < 5; ++r) {
         int pi = r, pj = r;
@@ -103,11 +125,9 @@ PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P) {
         for (int j = 0; j < 9; ++j) basis[k][j] *= inv;
     }
     // ---- 3. E entries as linear polynomials in (x, y, z, 1)
-    double Ep[9][4];
     for (int e = 0; e < 9; ++e)
         for (int k = 0; k < 4; ++k) Ep[e][k] = basis[k][e];
     // ---- 4. EE' (symmetric, 6 entries) and its trace, degree 2
-    double EEt[3][3][10];
     for (int r = 0; r < 3; ++r)
         for (int c = r; c < 3; ++c) {
             for (int k = 0; k < 10; ++k) EEt[r][c][k] = 0.0;
@@ -116,12 +136,9 @@ PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P) {
     for (int r = 1; r < 3; ++r)
         for (int c = 0; c < r; ++c)
             for (int k = 0; k < 10; ++k) EEt[r][c][k] = EEt[c][r][k];
-    double tr[10];
     for (int k = 0; k < 10; ++k) tr[k] = EEt[0][0][k] + EEt[1][1][k] + EEt[2][2][k];
     // ---- 5. the 10 cubic constraints, columns in Nistér's order
-    double A[10][20];
     {
-        double tmp[20], d2[10];
         auto put = [&](int row) { for (int c = 0; c < 20; ++c) A[row][c] = tmp[kNister[c]]; };
         for (int k = 0; k < 20; ++k) tmp[k] = 0.0;
         const int cof[3][4] = {{1, 5, 2, 4}, {2, 3, 0, 5}, {0, 4, 1, 3}};   // det E = sum_c (minor_c) * E[2][c]
@@ -258,7 +275,8 @@ PH_HD inline bool root_to_E(const Poly5& P, cplx z, float* e9) {
 // eo = 90 floats (10 slots, slot k = root k), pre-zeroed by the caller.  Returns the number of real solutions.
 PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
     Poly5 P;
-    if (!build_polynomial(pts, P)) return 0;
+    Work5 w;
+    if (!build_polynomial(pts, P, w)) return 0;
     const int n = P.n;
     cplx z[10];
     for (int k = 0; k < n; ++k) z[k] = aberth_start(P, k);
