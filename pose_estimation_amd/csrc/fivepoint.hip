@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void fivepoint_roots_kernel(const ph5::Poly5* _
     const int n = P.n;
     const bool live = active && k < n;
     ph5::cplx z = live ? ph5::aberth_start(P, k) : ph5::cplx{0.0, 0.0};
-    for (int it = 0; it < 100; ++it) {
+    for (int it = 0; it < ph5::kAberthMaxIter; ++it) {
         ph5::cplx sum = {0.0, 0.0};
         for (int d = 1; d < 10; ++d) {
             int kk = k + d; kk = kk >= 10 ? kk - 10 : kk;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void fivepoint_roots_kernel(const ph5::Poly5* _
             const double zr = __shfl(z.re, src), zi = __shfl(z.im, src);
             if (kk < n) {
                 const ph5::cplx dd = {z.re - zr, z.im - zi};
-                const ph5::cplx inv = ph5::cdiv(ph5::cplx{1.0, 0.0}, dd);
+                const ph5::cplx inv = ph5::cinv(dd);
                 sum.re += inv.re; sum.im += inv.im;
             }
         }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void fivepoint_roots_kernel(const ph5::Poly5* _
             z.re -= w.re; z.im -= w.im;
             change = (fabs(w.re) + fabs(w.im)) / (fabs(z.re) + fabs(z.im) + 1e-30);
         }
-        if (__all(change < 1e-15)) break;                // wave-uniform exit
+        if (__all(change < ph5::kAberthTol)) break;                // wave-uniform exit
     }
     float e9[9];
     bool real = false;

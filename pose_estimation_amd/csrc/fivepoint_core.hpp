@@ -36,10 +36,11 @@ PH_HD inline void pmul_acc(const double* a, int na, const double* b, int nb, dou
 
 struct cplx { double re, im; };
 PH_HD inline cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-PH_HD inline cplx cdiv(cplx a, cplx b) {
-    const double d = b.re * b.re + b.im * b.im;
-    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+PH_HD inline cplx cinv(cplx b) {                       // 1/b with ONE real division
+    const double r = 1.0 / (b.re * b.re + b.im * b.im);
+    return {b.re * r, -b.im * r};
 }
+PH_HD inline cplx cdiv(cplx a, cplx b) { return cmul(a, cinv(b)); }
 
 
 // pts[r] = (x1, y1, x2, y2) of correspondence r; eo = 90 floats (10 slots), pre-zeroed by the caller.
@@ -204,6 +205,11 @@ PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P, Work5& w
     return true;
 }
 
+// Iteration control: the roots are polished by Newton steps on the real axis afterwards (root_to_E), so the
+// simultaneous iteration only has to separate them; 1e-13 relative is far inside Newton's basin.
+PH_HD_CONST int kAberthMaxIter = 60;
+PH_HD_CONST double kAberthTol = 1e-13;
+
 // Aberth-Ehrlich start values: n points on a circle of the geometric-mean root radius.
 PH_HD inline cplx aberth_start(const Poly5& P, int k) {
     double rad = pow(fabs(P.c[0] / P.c[P.n]) + 1e-300, 1.0 / P.n);
@@ -280,7 +286,7 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
     const int n = P.n;
     cplx z[10];
     for (int k = 0; k < n; ++k) z[k] = aberth_start(P, k);
-    for (int it = 0; it < 100; ++it) {
+    for (int it = 0; it < kAberthMaxIter; ++it) {
         cplx w[10];
         double worst = 0.0;
         for (int k = 0; k < n; ++k) {
@@ -288,7 +294,7 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
             for (int j = 0; j < n; ++j) {
                 if (j == k) continue;
                 const cplx d = {z[k].re - z[j].re, z[k].im - z[j].im};
-                const cplx inv = cdiv(cplx{1.0, 0.0}, d);
+                const cplx inv = cinv(d);
                 sum.re += inv.re; sum.im += inv.im;
             }
             w[k] = aberth_step(P, z[k], sum);
@@ -297,7 +303,7 @@ PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
             z[k].re -= w[k].re; z[k].im -= w[k].im;
             worst = fmax(worst, (fabs(w[k].re) + fabs(w[k].im)) / (fabs(z[k].re) + fabs(z[k].im) + 1e-30));
         }
-        if (worst < 1e-15) break;
+        if (worst < kAberthTol) break;
     }
     int ns = 0;
     for (int k = 0; k < n; ++k) ns += root_to_E(P, z[k], eo + 9 * k) ? 1 : 0;

@@ -1,19 +1,23 @@
 """Batched two-view relative-pose pipeline: the hot path north_star describes, end to end.
 
     match (L2 or Hamming, top-2) -> Lowe ratio test -> compact correspondences
-      -> score H essential-matrix hypotheses -> best hypothesis -> inlier mask
-      -> [host] decompose E into 4 (R, t) candidates
-      -> triangulate with all 4 + cheirality vote -> pose table row
+      -> Philox minimal samples -> 5-point solver (hypotheses) -> score H hypotheses
+      -> best hypothesis -> inlier mask                                         [front, device]
+      -> decompose the winning E into its 4 (R, t) candidates                   [host, 3x3 SVDs]
+      -> triangulate with all 4 + cheirality vote -> pose table row             [back, device]
 
 The reference's per-image loop (main.py:163-214) is what gets batched: one launch per stage
 handles B pairs; the only host round trip is the 3x3 SVD per pair that north_star leaves on
-the host (recoverPose-style decomposition).  Output: a [B, 16] float32 pose table
-(R row-major 9, t 3, inliers, matches, winning hypothesis, status) — the unit that is gathered
-across ranks.
+the host (recoverPose-style decomposition).  The pipeline is split at that round trip into
+`relative_pose_front` / `relative_pose_back` so a caller can enqueue the next batch's front
+before finishing the previous batch's back: the GPU then never waits for the host.
+Output: a [B, 16] float32 pose table (R row-major 9, t 3, inliers, matches, winning hypothesis,
+status) — the unit that is gathered across ranks.
 """
 from __future__ import annotations
 
-import numpy as np
+from dataclasses import dataclass, field
+
 import torch
 
 from . import geometry, matching, ransac, triangulation
@@ -21,18 +25,35 @@ from . import geometry, matching, ransac, triangulation
 STATUS_OK = 1.0
 STATUS_DEGENERATE = 0.0
 
+_R_COLS = [0, 1, 2, 4, 5, 6, 8, 9, 10]
+_T_COLS = [3, 7, 11]
 
-def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
-                        n_samples=410, seed=0):
-    """Run the pipeline for B pairs.
 
-    match: callable returning (idx, d1, d2) and a flag telling which ratio filter applies,
+@dataclass
+class Front:
+    """Device results of the front half plus the in-flight host copy of the winning E matrices."""
+    pts: tuple
+    n_match: torch.Tensor
+    E_hyp: torch.Tensor
+    best_idx: torch.Tensor
+    best_count: torch.Tensor
+    mask: torch.Tensor
+    E_best_host: torch.Tensor
+    copied: torch.cuda.Event
+    want_points: bool = False
+    extra: dict = field(default_factory=dict)
+
+
+def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
+                        n_samples=410, seed=0) -> Front:
+    """Everything up to the inlier mask, plus an asynchronous copy of the winning E of every pair.
+
+    match: callable returning (idx, d1, d2, kind) with kind "l2" or "hamming",
            e.g. ``lambda: (*matching.match_l2(...), "l2")``.
     kp_q/kp_t: [V, n, 2] normalised keypoints; view_q/view_t: int32 [B] (device) or None.
     E_hyp: [B, H, 9] float32 device tensor of essential-matrix hypotheses, or None: then they are
            generated on the device from `n_samples` Philox-drawn minimal samples of the pair's own
            matches by the 5-point solver (10 hypothesis slots per sample, H = 10*n_samples).
-    Returns dict(table [B,16] device f32, n_match, best_idx, best_count, mask, xyz (optional)).
     """
     idx, d1, d2, kind = match()
     keep = (matching.ratio_filter_l2 if kind == "l2" else matching.ratio_filter_hamming)(idx, d1, d2, ratio)
@@ -44,26 +65,45 @@ def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"])
     bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_essential(E_hyp, bi, *pts, thr_sq, m["n_match"])
-
-    # host: decomposition of the winning E of every pair (3x3 SVDs)
     B = E_hyp.shape[0]
-    E_best = E_hyp[torch.arange(B, device=E_hyp.device), bi.long()].reshape(B, 3, 3)
-    P1, P2, Rc, tc = geometry.candidate_projections(E_best.cpu().numpy())
-    dev = E_hyp.device
-    xyz, front = triangulation.triangulate(torch.from_numpy(P1).to(dev), torch.from_numpy(P2).to(dev), *pts,
-                                           n_valid=m["n_match"], mask=mask, want_points=want_points, want_front=True)
+    E_best = E_hyp[torch.arange(B, device=E_hyp.device), bi.long()]
+    host = torch.empty((B, 9), dtype=torch.float32, pin_memory=True)
+    host.copy_(E_best, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return Front(pts, m["n_match"], E_hyp, bi, bc, mask, host, ev, want_points)
+
+
+def relative_pose_back(f: Front):
+    """Host decomposition of the winning E matrices, 4-candidate triangulation + cheirality vote, pose table."""
+    f.copied.synchronize()
+    B = f.E_best_host.shape[0]
+    P1, P2, _, _ = geometry.candidate_projections(f.E_best_host.numpy().reshape(B, 3, 3))
+    dev = f.E_hyp.device
+    P1d = torch.from_numpy(P1).to(dev, non_blocking=True)
+    P2d = torch.from_numpy(P2).to(dev, non_blocking=True)
+    xyz, front = triangulation.triangulate(P1d, P2d, *f.pts, n_valid=f.n_match, mask=f.mask,
+                                           want_points=f.want_points, want_front=True)
     win = torch.argmax(front, dim=1)
-    win_h = win.cpu().numpy()
-    table = np.zeros((B, 16), np.float32)
-    table[:, :9] = Rc[np.arange(B), win_h].reshape(B, 9)
-    table[:, 9:12] = tc[np.arange(B), win_h]
-    table_d = torch.from_numpy(table).to(dev)
-    table_d[:, 12] = bc.float()
-    table_d[:, 13] = m["n_match"].float()
-    table_d[:, 14] = bi.float()
-    table_d[:, 15] = torch.where(bc >= 5, STATUS_OK, STATUS_DEGENERATE)
-    out = dict(table=table_d, E_hyp=E_hyp, n_match=m["n_match"], best_idx=bi, best_count=bc, mask=mask, front=front, win=win)
-    if want_points:
+    Pw = P2d[torch.arange(B, device=dev), win]                     # [B, 12] = rows of [R | t]
+    table = torch.empty((B, 16), dtype=torch.float32, device=dev)
+    table[:, :9] = Pw[:, _R_COLS]
+    table[:, 9:12] = Pw[:, _T_COLS]
+    table[:, 12] = f.best_count.float()
+    table[:, 13] = f.n_match.float()
+    table[:, 14] = f.best_idx.float()
+    table[:, 15] = torch.where(f.best_count >= 5, STATUS_OK, STATUS_DEGENERATE)
+    out = dict(table=table, E_hyp=f.E_hyp, n_match=f.n_match, best_idx=f.best_idx, best_count=f.best_count,
+               mask=f.mask, front=front, win=win)
+    if f.want_points:
         out["xyz"] = xyz[torch.arange(B, device=dev), win]
-        out["pts"] = pts
+        out["pts"] = f.pts
     return out
+
+
+def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
+                        n_samples=410, seed=0):
+    """front + back for one batch of B pairs.  Returns dict(table [B,16] device f32, n_match, best_idx,
+    best_count, mask, E_hyp, front, win and, with want_points, xyz / pts)."""
+    return relative_pose_back(relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio,
+                                                  want_points, n_samples, seed))
