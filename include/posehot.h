@@ -200,6 +200,15 @@ int ph_reprojection_error(const float* obj, const float* img, const double* pose
                           const double* K4, const double* dist5, const int32_t* n_valid,
                           int B, int N, double* err, double* stats, void* stream);
 
+/* Levenberg-Marquardt refinement of B poses on the distorted reprojection error: the iterative
+ * half of cv2.solvePnP(..., SOLVEPNP_ITERATIVE) at main.py:101-104 (== validate_pose.py:93-96),
+ * batched.  pose [B][6] f64 (rvec, tvec) holds the initial guess on entry
+ * and the refined pose on return; obj [B][N][3] f32, img [B][N][2] f32 (distorted pixels);
+ * rms [B] (may be NULL) = sqrt(mean squared residual); iters [B] (may be NULL) = iterations run. */
+int ph_refine_pose_lm(const float* obj, const float* img, const int32_t* n_valid, int B, int N,
+                      const double* K4, const double* dist5, int max_iters,
+                      double* pose, double* rms, int32_t* iters, void* stream);
+
 /* Inverse of the distortion model for 2-D points (pixels [n][2] f32 -> normalised, undistorted
  * [n][2] f32), `iters` fixed-point iterations in float64: the one-off undistort ahead of
  * ph_score_pnp / ph_score_essential. */

@@ -313,3 +313,42 @@ def summary_of_means(means):
     grade = "EXCELLENT" if m < 1.0 else "GOOD" if m < 2.0 else "FAIR" if m < 5.0 else "POOR"
     return {"mean": m, "max": float(np.max(means)), "min": float(np.min(means)), "std": float(np.std(means)),
             "grade": grade}
+
+
+# ---------------------------------------------------------------- Levenberg-Marquardt pose refinement (NumPy checker)
+def _lm_residual(p, obj, img, K, dist):
+    uv = project_points_np(obj, p[:3], p[3:], K, dist)
+    return (uv - img).reshape(-1)
+
+
+def refine_pose_lm_np(obj, img, pose0, K=CAMERA_MATRIX, dist=DIST_COEFFS, max_iters=50):
+    """Float64 LM on the distorted reprojection error with a central-difference Jacobian over (rvec, tvec):
+    the independent checker of ph_refine_pose_lm (different parametrisation, numeric derivatives).
+    Follows what cv2.solvePnP(SOLVEPNP_ITERATIVE) minimises (main.py:101-104).  Returns (pose [6], rms)."""
+    obj = np.asarray(obj, np.float64).reshape(-1, 3); img = np.asarray(img, np.float64).reshape(-1, 2)
+    pose = np.asarray(pose0, np.float64).copy()
+    lam = 1e-3
+    r = _lm_residual(pose, obj, img, K, dist); cost = r @ r
+
+    def jac(p):
+        J = np.empty((r.size, 6))
+        for k in range(6):
+            h = 1e-7 * max(1.0, abs(p[k])); d = np.zeros(6); d[k] = h
+            J[:, k] = (_lm_residual(p + d, obj, img, K, dist) - _lm_residual(p - d, obj, img, K, dist)) / (2 * h)
+        return J
+    J = jac(pose)
+    for _ in range(max_iters):
+        JtJ, g = J.T @ J, J.T @ r
+        step = np.linalg.solve(JtJ + lam * np.diag(np.diag(JtJ)), -g)
+        r2 = _lm_residual(pose + step, obj, img, K, dist); c2 = r2 @ r2
+        if c2 < cost:
+            done = (cost - c2) <= 1e-14 * max(cost, 1e-300)
+            pose, r, cost, lam = pose + step, r2, c2, max(lam / 10, 1e-12)
+            J = jac(pose)
+            if done:
+                break
+        else:
+            lam *= 10
+            if lam > 1e12:
+                break
+    return pose, float(np.sqrt(cost / len(obj)))

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ph_triangulate": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "ph_project_points": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "ph_reprojection_error": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "ph_refine_pose_lm": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ph_undistort_points": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
 }
 

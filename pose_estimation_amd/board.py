@@ -14,11 +14,11 @@ Error convention as in the reference: sentinel returns (None, None, n), never ex
 "no markers / too few points / solver failed" (main.py:91-107).
 
 Where the arithmetic runs: projection and reprojection-error statistics are batched float64
-HIP kernels (csrc/board.hip) behind the C ABI.  The pose solve itself follows
+HIP kernels (csrc/board.hip) behind the C ABI.  The pose solve follows
 cv2.solvePnP(SOLVEPNP_ITERATIVE) on coplanar points as documented — homography-based initial
-pose, then Levenberg-Marquardt on the distorted reprojection error — and is the per-item
-refinement that north_star leaves on the host (float64 NumPy, <= 308 points); cv2 is not
-installed here, so this step is "parity unpinned" against OpenCV's exact iteration schedule.
+pose (host, one 9x9 SVD per image), then Levenberg-Marquardt on the distorted reprojection
+error, which runs batched on the GPU (ph_refine_pose_lm, float64, one block per image); cv2 is
+not installed here, so this step is "parity unpinned" against OpenCV's exact iteration schedule.
 """
 from __future__ import annotations
 
@@ -296,64 +296,71 @@ def _homography_pose(obj, xy):
     return R, t
 
 
-def _residual_jac(pose, obj, img, K, dist):
-    """Distorted reprojection residual (2n) and its analytic-by-differences Jacobian (2n x 6)."""
-    def f(p):
-        R = rodrigues(p[:3])
-        Xc = obj @ R.T + p[3:]
-        x, y = Xc[:, 0] / Xc[:, 2], Xc[:, 1] / Xc[:, 2]
-        k1, k2, p1, p2, k3 = dist
-        r2 = x * x + y * y
-        g = 1 + k1 * r2 + k2 * r2 * r2 + k3 * r2 * r2 * r2
-        xd = x * g + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
-        yd = y * g + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
-        return np.stack([K[0, 0] * xd + K[0, 2] - img[:, 0], K[1, 1] * yd + K[1, 2] - img[:, 1]], axis=1).reshape(-1)
-    r = f(pose)
-    J = np.empty((r.size, 6))
-    for k in range(6):
-        h = 1e-7 * max(1.0, abs(pose[k]))
-        d = np.zeros(6); d[k] = h
-        J[:, k] = (f(pose + d) - f(pose - d)) / (2 * h)
-    return r, J
+def refine_pose_lm_batched(obj, img, pose, n_valid=None, camera_matrix=CAMERA_MATRIX, dist_coeffs=DIST_COEFFS,
+                           max_iters=30):
+    """Batched Levenberg-Marquardt on the distorted reprojection error (device, float64).
+
+    obj [B,N,3] f32, img [B,N,2] f32, pose [B,6] f64 initial (rvec, tvec) — all on the GPU.
+    Returns (pose [B,6] refined, rms [B], iters [B] int32)."""
+    lib = L.load()
+    obj, img = L.dev(obj, torch.float32, "obj"), L.dev(img, torch.float32, "img")
+    pose = L.dev(pose, torch.float64, "pose").clone()
+    B, N = obj.shape[0], obj.shape[1]
+    K4, d5 = _cam_tensors(camera_matrix, dist_coeffs, obj.device)
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    rms = torch.zeros((B,), dtype=torch.float64, device=obj.device)
+    iters = torch.zeros((B,), dtype=torch.int32, device=obj.device)
+    L.check(lib.ph_refine_pose_lm(L.ptr(obj), L.ptr(img), L.ptr(n_valid), B, N, L.ptr(K4), L.ptr(d5), int(max_iters),
+                                  L.ptr(pose), L.ptr(rms), L.ptr(iters), L.stream_ptr()), "ph_refine_pose_lm")
+    return pose, rms, iters
 
 
-def solve_pnp_iterative(obj_points, img_points, camera_matrix, dist_coeffs, max_iters=50):
-    """cv2.solvePnP(..., flags=SOLVEPNP_ITERATIVE) for a coplanar (z = 0) point set.
-
-    Returns (success, rvec (3,1) f64, tvec (3,1) f64).
-    """
+def initial_board_pose(obj_points, img_points, camera_matrix, dist_coeffs):
+    """Homography-based initial pose of a coplanar (z = 0) point set: (rvec, tvec) float64 [6], or None."""
     obj = np.asarray(obj_points, np.float64).reshape(-1, 3)
     img = np.asarray(img_points, np.float64).reshape(-1, 2)
     K = np.asarray(camera_matrix, np.float64)
     dist = np.asarray(dist_coeffs, np.float64).reshape(-1)[:5]
     if len(obj) < 4 or len(obj) != len(img):
-        return False, None, None
+        return None
     try:
         R0, t0 = _homography_pose(obj, _undistort_np(img, K, dist))
     except np.linalg.LinAlgError:
-        return False, None, None
+        return None
     pose = np.concatenate([rotation_to_rvec(R0), t0])
-    lam = 1e-3
-    r, J = _residual_jac(pose, obj, img, K, dist)
-    cost = r @ r
-    for _ in range(max_iters):
-        JtJ, g = J.T @ J, J.T @ r
-        step = np.linalg.solve(JtJ + lam * np.diag(np.diag(JtJ)), -g)
-        r2, J2 = _residual_jac(pose + step, obj, img, K, dist)
-        c2 = r2 @ r2
-        if c2 < cost:
-            pose, r, J = pose + step, r2, J2
-            done = (cost - c2) <= 1e-12 * max(cost, 1e-30) or np.linalg.norm(step) < 1e-12
-            cost, lam = c2, max(lam / 10, 1e-12)
-            if done:
-                break
-        else:
-            lam *= 10
-            if lam > 1e12:
-                break
-    if not np.all(np.isfinite(pose)):
-        return False, None, None
-    return True, pose[:3].reshape(3, 1), pose[3:].reshape(3, 1)
+    return pose if np.all(np.isfinite(pose)) else None
+
+
+def solve_pnp_iterative_batched(items, camera_matrix, dist_coeffs, max_iters=30):
+    """cv2.solvePnP(..., SOLVEPNP_ITERATIVE) for many coplanar point sets in one launch.
+
+    items: list of (obj_points, img_points).  Returns a list of (success, rvec (3,1), tvec (3,1)):
+    homography initial pose per item on the host (a 9x9 SVD each), then ONE batched
+    Levenberg-Marquardt launch on the GPU (ph_refine_pose_lm)."""
+    inits = [initial_board_pose(o, i, camera_matrix, dist_coeffs) for o, i in items]
+    good = [k for k, p in enumerate(inits) if p is not None]
+    out = [(False, None, None)] * len(items)
+    if not good:
+        return out
+    dev = _device()
+    N = max(len(np.asarray(items[k][0]).reshape(-1, 3)) for k in good)
+    obj = np.zeros((len(good), N, 3), np.float32); img = np.zeros((len(good), N, 2), np.float32)
+    nv = np.zeros(len(good), np.int32); pose = np.zeros((len(good), 6), np.float64)
+    for r, k in enumerate(good):
+        o = np.asarray(items[k][0], np.float32).reshape(-1, 3); i = np.asarray(items[k][1], np.float32).reshape(-1, 2)
+        nv[r] = len(o); obj[r, :len(o)] = o; img[r, :len(o)] = i; pose[r] = inits[k]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    refined, _, _ = refine_pose_lm_batched(t(obj), t(img), t(pose), t(nv), camera_matrix, dist_coeffs, max_iters)
+    refined = refined.cpu().numpy()
+    for r, k in enumerate(good):
+        ok = bool(np.all(np.isfinite(refined[r])))
+        out[k] = (ok, refined[r, :3].reshape(3, 1).copy(), refined[r, 3:].reshape(3, 1).copy()) if ok else (False, None, None)
+    return out
+
+
+def solve_pnp_iterative(obj_points, img_points, camera_matrix, dist_coeffs, max_iters=30):
+    """cv2.solvePnP(..., flags=SOLVEPNP_ITERATIVE) for one coplanar point set: (success, rvec, tvec)."""
+    return solve_pnp_iterative_batched([(obj_points, img_points)], camera_matrix, dist_coeffs, max_iters)[0]
 
 
 def estimate_board_pose(corners, ids, board, camera_matrix, dist_coeffs):

@@ -138,6 +138,244 @@ __global__ __launch_bounds__(256) void undistort_kernel(const float* __restrict_
     xy[2 * i + 1] = (float)y;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Levenberg-Marquardt refinement of a pose on the distorted reprojection error — the iterative
+// half of cv2.solvePnP(SOLVEPNP_ITERATIVE) (main.py:101-104).  One 256-thread block per item,
+// float64.  Parametrisation: left-multiplicative rotation update R <- exp([dw]x) R, t <- t + dt,
+// so dXc/ddw = -[R X]x and dXc/ddt = I; the 2x3 Jacobian of (u, v) w.r.t. Xc is analytic.
+// Per iteration: pass 1 accumulates J'J (21 unique), J'r (6) and the cost over the item's points
+// (wave shuffles, then LDS across the 4 waves); thread 0 solves the damped 6x6 system (Cholesky);
+// pass 2 evaluates the cost at the candidate pose; accept -> lambda/10, reject -> lambda*10.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void exp_so3(const double* w, double (&R)[9]) { rodrigues(w, R); }
+
+__device__ __forceinline__ void mat3_mul(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+
+// rotation matrix -> rotation vector (angle in [0, pi])
+__device__ void log_so3(const double (&R)[9], double* w) {
+    const double tr = R[0] + R[4] + R[8];
+    const double c = fmin(fmax((tr - 1.0) * 0.5, -1.0), 1.0);
+    const double th = acos(c);
+    const double a0 = R[7] - R[5], a1 = R[2] - R[6], a2 = R[3] - R[1];
+    if (th < 1e-10) { w[0] = 0.5 * a0; w[1] = 0.5 * a1; w[2] = 0.5 * a2; return; }
+    if (3.141592653589793 - th < 1e-6) {
+        const double d0 = sqrt(fmax((R[0] + 1.0) * 0.5, 0.0)), d1 = sqrt(fmax((R[4] + 1.0) * 0.5, 0.0)),
+                     d2 = sqrt(fmax((R[8] + 1.0) * 0.5, 0.0));
+        double k[3];
+        if (d0 >= d1 && d0 >= d2) { k[0] = d0; k[1] = (R[1] + R[3]) * 0.25 / d0; k[2] = (R[2] + R[6]) * 0.25 / d0; }
+        else if (d1 >= d2) { k[1] = d1; k[0] = (R[1] + R[3]) * 0.25 / d1; k[2] = (R[5] + R[7]) * 0.25 / d1; }
+        else { k[2] = d2; k[0] = (R[2] + R[6]) * 0.25 / d2; k[1] = (R[5] + R[7]) * 0.25 / d2; }
+        const double sgn = (a0 * k[0] + a1 * k[1] + a2 * k[2]) < 0.0 ? -1.0 : 1.0;
+        w[0] = sgn * th * k[0]; w[1] = sgn * th * k[1]; w[2] = sgn * th * k[2];
+        return;
+    }
+    const double f = th / (2.0 * sin(th));
+    w[0] = f * a0; w[1] = f * a1; w[2] = f * a2;
+}
+
+// residual (ru, rv) of one point and, optionally, its 2x6 Jacobian w.r.t. (dw, dt)
+__device__ __forceinline__ void lm_point(const double (&R)[9], const double* t, const Cam& cam, const float* X3, const float* m2,
+                                         double& ru, double& rv, double (*J)[6]) {
+    const double X = X3[0], Y = X3[1], Z = X3[2];
+    const double rx = R[0] * X + R[1] * Y + R[2] * Z, ry = R[3] * X + R[4] * Y + R[5] * Z, rz = R[6] * X + R[7] * Y + R[8] * Z;
+    const double xc = rx + t[0], yc = ry + t[1], zc = rz + t[2];
+    const double iz = 1.0 / zc;
+    const double x = xc * iz, y = yc * iz, r2 = x * x + y * y;
+    const double g = 1 + cam.k1 * r2 + cam.k2 * r2 * r2 + cam.k3 * r2 * r2 * r2;
+    const double xd = x * g + 2 * cam.p1 * x * y + cam.p2 * (r2 + 2 * x * x);
+    const double yd = y * g + cam.p1 * (r2 + 2 * y * y) + 2 * cam.p2 * x * y;
+    ru = cam.fx * xd + cam.cx - (double)m2[0];
+    rv = cam.fy * yd + cam.cy - (double)m2[1];
+    if (!J) return;
+    const double dg = cam.k1 + 2 * cam.k2 * r2 + 3 * cam.k3 * r2 * r2;          // dg/dr2
+    // d(xd, yd)/d(x, y)
+    const double xdx = g + 2 * x * x * dg + 2 * cam.p1 * y + 6 * cam.p2 * x;
+    const double xdy = 2 * x * y * dg + 2 * cam.p1 * x + 2 * cam.p2 * y;
+    const double ydx = 2 * x * y * dg + 2 * cam.p1 * x + 2 * cam.p2 * y;
+    const double ydy = g + 2 * y * y * dg + 6 * cam.p1 * y + 2 * cam.p2 * x;
+    // d(x, y)/dXc = [iz 0 -x iz; 0 iz -y iz]
+    double A[2][3];
+    A[0][0] = cam.fx * xdx * iz; A[0][1] = cam.fx * xdy * iz; A[0][2] = -cam.fx * (xdx * x + xdy * y) * iz;
+    A[1][0] = cam.fy * ydx * iz; A[1][1] = cam.fy * ydy * iz; A[1][2] = -cam.fy * (ydx * x + ydy * y) * iz;
+    // dXc/ddw = -[RX]x = [[0, rz, -ry], [-rz, 0, rx], [ry, -rx, 0]];  dXc/ddt = I
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        J[k][0] = -A[k][1] * rz + A[k][2] * ry;
+        J[k][1] = A[k][0] * rz - A[k][2] * rx;
+        J[k][2] = -A[k][0] * ry + A[k][1] * rx;
+        J[k][3] = A[k][0]; J[k][4] = A[k][1]; J[k][5] = A[k][2];
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restrict__ obj, const float* __restrict__ img,
+                                                         const int32_t* __restrict__ n_valid, int N,
+                                                         const double* __restrict__ K4, const double* __restrict__ d5,
+                                                         int max_iters, double* __restrict__ pose, double* __restrict__ rms,
+                                                         int32_t* __restrict__ iters_out) {
+    __shared__ double red[4][28];
+    __shared__ double sh_R[9], sh_t[3], sh_Rc[9], sh_tc[3];
+    __shared__ double sh_cost;
+    __shared__ int sh_flag;                      // 0 continue, 1 converged/stop
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    const Cam cam = load_cam(K4, d5);
+    const float* O = obj + (size_t)b * N * 3;
+    const float* M = img + (size_t)b * N * 2;
+    double* P = pose + (size_t)b * 6;
+
+    if (tid == 0) {
+        double R0[9];
+        rodrigues(P, R0);
+        for (int k = 0; k < 9; ++k) sh_R[k] = R0[k];
+        for (int k = 0; k < 3; ++k) sh_t[k] = P[3 + k];
+        sh_flag = (nv < 3) ? 1 : 0;
+    }
+    __syncthreads();
+
+    double lambda = 1e-3, cost = 0.0;
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        if (sh_flag) break;
+        // ---- pass 1: normal equations at the current pose
+        double R[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = sh_R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = sh_t[k];
+        double acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+        for (int i = tid; i < nv; i += 256) {
+            double ru, rv, J[2][6];
+            lm_point(R, t, cam, O + 3 * i, M + 2 * i, ru, rv, J);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c = a; c < 6; ++c) acc[q++] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] += J[0][a] * ru + J[1][a] * rv;
+            acc[27] += ru * ru + rv * rv;
+        }
+#pragma unroll
+        for (int k = 0; k < 28; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 28; ++k) red[wave][k] = acc[k];
+        __syncthreads();
+        if (tid == 0) {
+            double s[28];
+            for (int k = 0; k < 28; ++k) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            cost = s[27];
+            sh_cost = cost;
+            // damped system (Marquardt scaling), Cholesky
+            double A[6][6], g[6], L[6][6], dlt[6];
+            int q = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int c = a; c < 6; ++c) { A[a][c] = s[q]; A[c][a] = s[q]; ++q; }
+            for (int a = 0; a < 6; ++a) { g[a] = -s[21 + a]; A[a][a] += lambda * A[a][a] + 1e-300; }
+            bool ok = true;
+            for (int a = 0; a < 6 && ok; ++a)
+                for (int c = 0; c <= a; ++c) {
+                    double v = A[a][c];
+                    for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
+                    if (a == c) { if (!(v > 0.0)) { ok = false; break; } L[a][a] = sqrt(v); }
+                    else L[a][c] = v / L[c][c];
+                }
+            if (ok) {
+                for (int a = 0; a < 6; ++a) { double v = g[a]; for (int k = 0; k < a; ++k) v -= L[a][k] * dlt[k]; dlt[a] = v / L[a][a]; }
+                for (int a = 5; a >= 0; --a) { double v = dlt[a]; for (int k = a + 1; k < 6; ++k) v -= L[k][a] * dlt[k]; dlt[a] = v / L[a][a]; }
+                double dR[9], Rn[9], Rcur[9];
+                exp_so3(dlt, dR);
+                for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
+                mat3_mul(dR, Rcur, Rn);
+                for (int k = 0; k < 9; ++k) sh_Rc[k] = Rn[k];
+                for (int k = 0; k < 3; ++k) sh_tc[k] = sh_t[k] + dlt[3 + k];
+                double n2 = 0; for (int a = 0; a < 6; ++a) n2 += dlt[a] * dlt[a];
+                sh_flag = (n2 < 1e-26) ? 1 : 0;
+            } else {
+                for (int k = 0; k < 9; ++k) sh_Rc[k] = sh_R[k];
+                for (int k = 0; k < 3; ++k) sh_tc[k] = sh_t[k];
+                sh_flag = 2;                                   // not positive definite: just raise lambda
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: cost at the candidate
+        double Rc[9], tc[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Rc[k] = sh_Rc[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tc[k] = sh_tc[k];
+        double c2 = 0.0;
+        for (int i = tid; i < nv; i += 256) {
+            double ru, rv;
+            lm_point(Rc, tc, cam, O + 3 * i, M + 2 * i, ru, rv, nullptr);
+            c2 += ru * ru + rv * rv;
+        }
+        c2 = wave_sum(c2);
+        if (lane == 0) red[wave][0] = c2;
+        __syncthreads();
+        const double cnew = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        const double cold = sh_cost;
+        const int flag = sh_flag;
+        __syncthreads();
+        if (flag != 2 && cnew < cold) {                        // uniform decision: every thread sees the same numbers
+            if (tid == 0) {
+                for (int k = 0; k < 9; ++k) sh_R[k] = sh_Rc[k];
+                for (int k = 0; k < 3; ++k) sh_t[k] = sh_tc[k];
+                if ((cold - cnew) <= 1e-14 * fmax(cold, 1e-300)) sh_flag = 1;
+            }
+            lambda = fmax(lambda * 0.1, 1e-12);
+            cost = cnew;
+        } else {
+            lambda *= 10.0;
+            cost = cold;
+            if (tid == 0) sh_flag = (lambda > 1e12 || flag == 1) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    // ---- cost at the pose that is returned (also covers max_iters == 0 and early stops)
+    {
+        double R[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = sh_R[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = sh_t[k];
+        double c2 = 0.0;
+        for (int i = tid; i < nv; i += 256) {
+            double ru, rv;
+            lm_point(R, t, cam, O + 3 * i, M + 2 * i, ru, rv, nullptr);
+            c2 += ru * ru + rv * rv;
+        }
+        c2 = wave_sum(c2);
+        if (lane == 0) red[wave][0] = c2;
+        __syncthreads();
+        cost = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+    }
+    if (tid == 0) {
+        if (it > 0) {                               // no iteration ran: the caller's pose stays bit-for-bit
+            double R[9], w[3];
+            for (int k = 0; k < 9; ++k) R[k] = sh_R[k];
+            log_so3(R, w);
+            P[0] = w[0]; P[1] = w[1]; P[2] = w[2]; P[3] = sh_t[0]; P[4] = sh_t[1]; P[5] = sh_t[2];
+        }
+        if (rms) rms[b] = nv > 0 ? sqrt(cost / nv) : 0.0;
+        if (iters_out) iters_out[b] = it;
+    }
+}
+
 }  // namespace
 
 extern "C" int ph_project_points(const float* obj, const double* pose, const double* K4, const double* dist5,
@@ -169,5 +407,16 @@ extern "C" int ph_undistort_points(const float* uv, const double* K4, const doub
     if (!uv || !K4 || !dist5 || !xy_norm) return PH_ERR_INVALID_ARG;
     hipLaunchKernelGGL(undistort_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, uv, K4,
                        dist5, n, iters, xy_norm);
+    return ph_launch_status();
+}
+
+extern "C" int ph_refine_pose_lm(const float* obj, const float* img, const int32_t* n_valid, int B, int N,
+                                 const double* K4, const double* dist5, int max_iters, double* pose, double* rms,
+                                 int32_t* iters, void* stream) {
+    if (B < 0 || N < 0 || max_iters < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!pose || !K4 || !dist5 || (N > 0 && (!obj || !img))) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(refine_pose_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, obj, img, n_valid, N, K4, dist5,
+                       max_iters, pose, rms, iters);
     return ph_launch_status();
 }

@@ -32,15 +32,6 @@ def test_match_image_points_shapes_and_sentinels():
     assert r == (None, None, 1)
 
 
-def test_estimate_board_pose_recovers_synthetic_pose():
-    _, b = board.create_aruco_board()
-    for v in synthetic.board_views(3, seed=9, noise_px=0.3):
-        rvec, tvec, n = board.estimate_board_pose(v["corners"], v["ids"], b, board.CAMERA_MATRIX, board.DIST_COEFFS)
-        assert n == 77 and rvec.shape == (3, 1) and tvec.shape == (3, 1) and rvec.dtype == np.float64
-        assert geometry.rotation_angle_deg(board.rodrigues(rvec), v["R"]) < 0.05
-        assert np.linalg.norm(tvec.flatten() - v["t"]) < 5e-4
-
-
 def test_camera_inversion_and_quaternion_order():
     d = json.load(open(os.path.join(G, "quaternions.json")))
     for c in d["cases"][:20]:

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import oracle as orc
-from pose_estimation_amd import board, synthetic
+from pose_estimation_amd import board, geometry, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -65,3 +65,55 @@ def test_undistort_inverts_distortion(device):
     uv = synthetic.distort_project(np.concatenate([xy, np.ones((5000, 1))], axis=1)).astype(np.float32)
     out = board.undistort_points(_t(uv, device), iters=20).cpu().numpy()
     assert np.abs(out - xy).max() < 2e-6
+
+
+def test_estimate_board_pose_recovers_synthetic_pose(device):
+    """main.py:86-109 through the reference-named function: homography init (host) + device LM."""
+    _, b = board.create_aruco_board()
+    for v in synthetic.board_views(3, seed=9, noise_px=0.3):
+        rvec, tvec, n = board.estimate_board_pose(v["corners"], v["ids"], b, board.CAMERA_MATRIX, board.DIST_COEFFS)
+        assert n == 77 and rvec.shape == (3, 1) and tvec.shape == (3, 1) and rvec.dtype == np.float64
+        assert geometry.rotation_angle_deg(board.rodrigues(rvec), v["R"]) < 0.05
+        assert np.linalg.norm(tvec.flatten() - v["t"]) < 5e-4
+
+
+def test_refine_pose_lm_matches_numpy_lm(device):
+    """Device LM (analytic Jacobian, SO(3) update) vs the oracle's NumPy LM (central differences over rvec):
+    both must land in the same minimum — pose within 1e-6, rms within 1e-9 px — from a perturbed start,
+    on ragged point counts (n_valid), and report an rms in the EXCELLENT band."""
+    vs = _views()
+    B = len(vs)
+    obj = np.stack([v[0] for v in vs]); img = np.stack([v[1] for v in vs])
+    n_valid = np.array([308, 308, 300, 8, 308, 4, 308, 200], np.int32)
+    rng = np.random.default_rng(5)
+    pose0 = np.stack([np.concatenate([v[2], v[3]]) for v in vs])
+    pose0[:, :3] += rng.normal(0, 0.05, (B, 3)); pose0[:, 3:] += rng.normal(0, 0.02, (B, 3))
+    pose, rms, iters = board.refine_pose_lm_batched(_t(obj, device), _t(img, device), _t(pose0, device),
+                                                    _t(n_valid, device), max_iters=50)
+    pose, rms, iters = pose.cpu().numpy(), rms.cpu().numpy(), iters.cpu().numpy()
+    for b in range(B):
+        nv = n_valid[b]
+        rp, rrms = orc.refine_pose_lm_np(obj[b, :nv], img[b, :nv], pose0[b], max_iters=100)
+        assert geometry.rotation_angle_deg(board.rodrigues(pose[b, :3]), board.rodrigues(rp[:3])) < 1e-4, (b, pose[b], rp)
+        assert np.abs(pose[b, 3:] - rp[3:]).max() < 1e-6, (b, pose[b], rp)
+        assert abs(rms[b] - rrms) < 1e-7, (b, rms[b], rrms)
+        # the rms the kernel reports is the rms of the oracle's residuals at the pose it returns
+        rerr, _ = orc.reprojection_error(obj[b, :nv], img[b, :nv], pose[b, :3], pose[b, 3:], orc.K4, orc.DIST_COEFFS)
+        assert abs(np.sqrt((rerr ** 2).mean()) - rms[b]) < 1e-8
+        assert 0 < iters[b] <= 50
+    assert rms[0] < 1.0
+
+
+def test_refine_pose_lm_edge_cases(device):
+    """Zero valid points: pose returned unchanged, rms 0, iters 0.  max_iters 0: pose unchanged, rms of the start."""
+    vs = _views()[:2]
+    obj = np.stack([v[0] for v in vs]); img = np.stack([v[1] for v in vs])
+    pose0 = np.stack([np.concatenate([v[2], v[3]]) for v in vs]); pose0[:, 3:] += 0.01
+    nv = np.array([0, 308], np.int32)
+    pose, rms, iters = board.refine_pose_lm_batched(_t(obj, device), _t(img, device), _t(pose0, device), _t(nv, device))
+    assert np.array_equal(pose[0].cpu().numpy(), pose0[0]) and rms[0].item() == 0.0 and iters[0].item() == 0
+    assert np.abs(pose[1, 3:].cpu().numpy() - vs[1][3]).max() < 5e-4
+    pose, rms, iters = board.refine_pose_lm_batched(_t(obj, device), _t(img, device), _t(pose0, device), None, max_iters=0)
+    assert np.abs(pose.cpu().numpy() - pose0).max() < 1e-12 and iters.sum().item() == 0
+    rerr, _ = orc.reprojection_error(obj[1], img[1], pose0[1, :3], pose0[1, 3:], orc.K4, orc.DIST_COEFFS)
+    assert abs(np.sqrt((rerr ** 2).mean()) - rms[1].item()) < 1e-8

@@ -24,7 +24,7 @@ def _worker(rank, world, port, n_items, q):
     assert len(ids) == sharding.shard_size(n_items, rank, world)
     local = torch.stack([ids.float() * 10 + c for c in range(16)], dim=1) if len(ids) else torch.zeros((0, 16))
     full = sharding.gather_pose_table(local, n_items)
-    q.put((rank, full))
+    q.put((rank, full.numpy().copy()))   # by value: a shared-memory tensor handle dies with the sender
     dist.barrier()
     dist.destroy_process_group()
 
@@ -43,7 +43,7 @@ def test_shard_and_gather_world2(n_items):
         assert p.exitcode == 0
     want = torch.stack([torch.arange(n_items).float() * 10 + c for c in range(16)], dim=1)
     for r in range(world):
-        assert torch.equal(got[r], want)
+        assert torch.equal(torch.from_numpy(got[r]), want)
 
 
 def test_shard_indices_cover_everything_once():
