@@ -136,6 +136,18 @@ int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, co
                            const int32_t* samples, int B, int S, int N,
                            float* E, int32_t* n_solutions, void* ws, size_t ws_bytes, void* stream);
 
+/* P3P minimal solver (float64 inside, one thread per sample): absolute pose from three 3-D points and
+ * their image points.  samples is [B][S][3] (indices into the item's N correspondences); (u, v) are
+ * normalised, undistorted image coordinates (ph_undistort_points).  P is [B][S*4][12] f32, 16-byte
+ * aligned: sample s owns hypothesis slots 4s .. 4s+3 (slot = root index of the quartic); a solution is
+ * the row-major 3x4 matrix K [R | t] when K4 = (fx, fy, cx, cy) is given — ready for ph_score_pnp on
+ * undistorted pixels — or [R | t] when K4 is NULL (normalised coordinates); every other slot is
+ * all-zero (w = 0: it scores zero inliers).  n_solutions ([B][S], may be NULL) = solutions per sample.
+ * No reference counterpart (main.py:101-104 calls cv2.solvePnP on all points); SURVEY.md §8f item 1. */
+int ph_solve_p3p(const float* X, const float* Y, const float* Z, const float* u, const float* v,
+                 const int32_t* samples, int B, int S, int N, const double* K4,
+                 float* P, int32_t* n_solutions, void* stream);
+
 /* Sampson distance of (x1,y1)->(x2,y2) (normalised image coordinates) under E (row-major 9):
  * inlier iff (x2' E x1)^2 < thr_sq * ((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2). */
 int ph_score_essential(const float* E, const float* x1, const float* y1,

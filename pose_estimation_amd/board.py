@@ -376,6 +376,28 @@ def estimate_board_pose(corners, ids, board, camera_matrix, dist_coeffs):
     return rvec, tvec, len(ids)
 
 
+def estimate_board_poses(detections, board, camera_matrix, dist_coeffs):
+    """estimate_board_pose for a list of (corners, ids) with ONE refinement launch for all of them.
+
+    Same guards and sentinels per item as main.py:86-109: returns [(rvec, tvec, num_markers), ...]."""
+    out, items, where = [], [], []
+    for k, (corners, ids) in enumerate(detections):
+        if ids is None or len(ids) == 0:
+            out.append((None, None, 0))
+            continue
+        out.append((None, None, len(ids)))
+        obj_points, img_points = board.matchImagePoints(corners, ids)
+        if obj_points is None or len(obj_points) < 4:
+            continue
+        items.append((obj_points, img_points))
+        where.append(k)
+    if items:
+        for k, (success, rvec, tvec) in zip(where, solve_pnp_iterative_batched(items, camera_matrix, dist_coeffs)):
+            if success:
+                out[k] = (rvec, tvec, out[k][2])
+    return out
+
+
 def create_board_3d_points(board_width_m, board_height_m):
     """validate_pose.py:104-178 — point sets of the validation overlay (float32 where the reference's are)."""
     points = {}

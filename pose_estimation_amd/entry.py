@@ -2,7 +2,8 @@
 
 They keep the reference's printed line formats and result-record keys (SURVEY.md §8 rows a-7,
 a-8; main.py:198-214, 439-463; validate_pose.py:374-375, 390-410) while batching the per-image
-arithmetic: all images' reprojection statistics come from one ph_reprojection_error launch.
+arithmetic: all images' poses come from one ph_refine_pose_lm launch and all reprojection
+statistics from one ph_reprojection_error launch.
 
 Detections.  The reference's front end (cv2.imread + ArucoDetector, main.py:168-178) is out of
 scope and cv2 is not installed here, so detections come from, in this order:
@@ -74,7 +75,9 @@ def save_detections(path, dets):
 def process_detections(dets, board, camera_matrix, dist_coeffs, verbose=True):
     """The loop of main.py:163-214 on detections: result records with the reference's 12 keys."""
     results = []
-    for d in dets:
+    # all images' poses in one Levenberg-Marquardt launch; the loop below only formats
+    poses = bd.estimate_board_poses([(d["corners"], d["ids"]) for d in dets], board, camera_matrix, dist_coeffs)
+    for d, (rvec, tvec, num_markers) in zip(dets, poses):
         filename, corners, ids = d["filename"], d["corners"], d["ids"]
         if verbose:
             print(f"\n🔍 Processing: {filename}")
@@ -84,7 +87,6 @@ def process_detections(dets, board, camera_matrix, dist_coeffs, verbose=True):
             continue
         if verbose:
             print(f"  ✓ Detected {len(ids)} markers: {np.asarray(ids).flatten().tolist()}")
-        rvec, tvec, num_markers = bd.estimate_board_pose(corners, ids, board, camera_matrix, dist_coeffs)
         if rvec is None:
             if verbose:
                 print("  ⚠️ Could not estimate pose")

@@ -56,6 +56,26 @@ def solve_essential_5pt(x1, y1, x2, y2, samples, want_counts=False):
     return (E, ns) if want_counts else E
 
 
+def solve_p3p(X, Y, Z, u, v, samples, K4=None, want_counts=False):
+    """P3P solver on the device.  samples int32 ``[B, S, 3]``; (u, v) normalised undistorted coordinates ->
+    P ``[B, 4*S, 12]`` float32 (4 slots per sample, slot = root index, empty slots all-zero): ``K [R|t]`` when
+    K4 = (fx, fy, cx, cy) (float64 device tensor) is given, else ``[R|t]``.  Optionally the solution counts ``[B, S]``."""
+    lib = L.load()
+    X, Y, Z, u, v = _pts((X, Y, Z, u, v), ("X", "Y", "Z", "u", "v"))
+    B, N = X.shape
+    samples = L.dev(samples, torch.int32, "samples")
+    if samples.dim() != 3 or samples.shape[0] != B or samples.shape[2] != 3:
+        raise ValueError("samples must be [B, S, 3]")
+    if K4 is not None:
+        K4 = L.dev(K4, torch.float64, "K4")
+    S = samples.shape[1]
+    P = torch.empty((B, 4 * S, 12), dtype=torch.float32, device=X.device)
+    ns = torch.empty((B, S), dtype=torch.int32, device=X.device) if want_counts else None
+    L.check(lib.ph_solve_p3p(L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(samples), B, S, N, L.ptr(K4),
+                             L.ptr(P), L.ptr(ns), L.stream_ptr()), "ph_solve_p3p")
+    return (P, ns) if want_counts else P
+
+
 def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None):
     """Inlier count of every E hypothesis (Sampson error < thr).  Returns int32 ``[B, H]``."""
     lib = L.load()

@@ -25,6 +25,11 @@ def rot_y(a):
     return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
 
 
+def rot_x(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+
 def look_at(C, target, up=(0.0, 0.0, 1.0)):
     """World->camera rotation of a camera at C looking at target (camera +Z forward, +Y down)."""
     C, target, up = (np.asarray(v, np.float64) for v in (C, target, up))

@@ -77,6 +77,17 @@ def test_estimate_board_pose_recovers_synthetic_pose(device):
         assert np.linalg.norm(tvec.flatten() - v["t"]) < 5e-4
 
 
+def test_estimate_board_poses_batched_equals_per_image(device):
+    _, b = board.create_aruco_board()
+    vs = synthetic.board_views(5, seed=3, noise_px=0.3, drop=0.4)
+    dets = [(v["corners"], v["ids"]) for v in vs] + [((), None), (vs[0]["corners"][:1], np.array([[999]], np.int32))]
+    got = board.estimate_board_poses(dets, b, board.CAMERA_MATRIX, board.DIST_COEFFS)
+    assert got[5] == (None, None, 0) and got[6] == (None, None, 1)
+    for v, (rvec, tvec, n) in zip(vs, got):
+        r1, t1, n1 = board.estimate_board_pose(v["corners"], v["ids"], b, board.CAMERA_MATRIX, board.DIST_COEFFS)
+        assert n == n1 == len(v["ids"]) and np.array_equal(rvec, r1) and np.array_equal(tvec, t1)
+
+
 def test_refine_pose_lm_matches_numpy_lm(device):
     """Device LM (analytic Jacobian, SO(3) update) vs the oracle's NumPy LM (central differences over rvec):
     both must land in the same minimum — pose within 1e-6, rms within 1e-9 px — from a perturbed start,

@@ -118,3 +118,75 @@ def test_generated_hypotheses_win_ransac(device):
     Rc, tc = geometry.decompose_essential(Eb[None])
     err = min(geometry.rotation_angle_deg(Rc[0, c], R) + geometry.direction_angle_deg(tc[0, c], t) for c in range(4))
     assert err < 0.5      # a minimal-sample model (5 noisy points), before any refinement
+
+
+# ------------------------------------------------------------------------------------------- P3P
+from oracle import p3p as op  # noqa: E402
+
+
+def _pnp_scene(seed, n, noise=0.0):
+    rng = np.random.default_rng(seed)
+    R = synthetic.rot_y(np.deg2rad(25.0)) @ synthetic.rot_x(np.deg2rad(-15.0))
+    t = np.array([0.2, -0.1, 4.0])
+    X = rng.uniform(-1, 1, (n, 3))
+    Xc = X @ R.T + t
+    xy = Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, noise, (n, 2))
+    return X.astype(np.float32), xy.astype(np.float32), R, t
+
+
+@pytest.mark.parametrize("noise", [0.0, 1.0 / 3108.95])
+def test_p3p_solutions_are_solutions_and_match_numpy(device, noise):
+    """Every device P3P output is a rotation + translation that maps the three sample points onto their bearings
+    with positive depth (the definition of a P3P solution, checked in float64 by the oracle), the solution set
+    agrees with the NumPy solver (np.roots + Kabsch) and, on noise-free data, contains the true pose."""
+    n, S = 400, 300
+    X, xy, R, t = _pnp_scene(11, n, noise)
+    nv = _t(np.array([n], np.int32), device)
+    samples = ransac.sample_minimal(5, nv, n, S, m=3)
+    P, ns = ransac.solve_p3p(*(_t(X[:, k][None], device) for k in range(3)), _t(xy[:, 0][None], device),
+                             _t(xy[:, 1][None], device), samples, want_counts=True)
+    P, ns, smp = P.cpu().numpy()[0].reshape(S, 4, 3, 4), ns.cpu().numpy()[0], samples.cpu().numpy()[0]
+    f_all = op.bearings(xy)
+    found = matched = total = same_count = 0
+    for s in range(S):
+        Xs, fs = X[smp[s]].astype(np.float64), f_all[smp[s]]
+        sols = [p for p in P[s] if np.any(p != 0)]
+        assert len(sols) == ns[s] and ns[s] <= 4
+        for p in sols:
+            orth, det, depth, mism = op.check_solution(p[:, :3].astype(np.float64), p[:, 3].astype(np.float64), Xs, fs)
+            assert orth < 1e-5 and abs(det - 1) < 1e-5 and depth > 0 and mism < 2e-5      # f32 storage of an f64 result
+        ref = op.solve_p3p(Xs, fs)
+        same_count += len(ref) == len(sols)
+        for Rr, tr in ref:
+            total += 1
+            matched += any(np.abs(p[:, :3] - Rr).max() < 1e-4 and np.abs(p[:, 3] - tr).max() < 1e-4 * max(1, np.abs(tr).max())
+                           for p in sols)
+        found += any(np.abs(p[:, :3] - R).max() < 2e-3 and np.abs(p[:, 3] - t).max() < 2e-2 for p in sols)
+    assert matched >= 0.99 * total and same_count >= 0.97 * S
+    if noise == 0.0:
+        assert found >= 0.99 * S     # f32 inputs: the true pose is reproduced to input precision
+
+
+def test_p3p_camera_matrix_output_and_degenerate_samples(device):
+    """K4 given: P = K [R|t], so ph_score_pnp on pixels counts every noise-free point as an inlier for the best
+    hypothesis.  Samples with an invalid index (-1) or coincident points give all-zero slots and count 0."""
+    n, S = 300, 64
+    X, xy, R, t = _pnp_scene(12, n)
+    K4 = np.array([3108.95, 3101.48, 1129.30, 1940.89])
+    pix = (xy.astype(np.float64) * K4[:2] + K4[2:]).astype(np.float32)
+    nv = _t(np.array([n], np.int32), device)
+    samples = ransac.sample_minimal(9, nv, n, S, m=3).clone()
+    samples[0, 0, 1] = -1
+    samples[0, 1, 2] = samples[0, 1, 0]
+    d = lambda a: _t(a[None], device)
+    Xd, Yd, Zd = d(X[:, 0]), d(X[:, 1]), d(X[:, 2])
+    P, ns = ransac.solve_p3p(Xd, Yd, Zd, d(xy[:, 0]), d(xy[:, 1]), samples, K4=_t(K4, device), want_counts=True)
+    assert ns[0, 0].item() == 0 and ns[0, 1].item() == 0 and not P[0, :8].any().item()
+    cnt = ransac.score_pnp(P, Xd, Yd, Zd, d(pix[:, 0]), d(pix[:, 1]), 1.0)
+    bi, bc = ransac.select_best(cnt)
+    assert bc.item() >= n - 2
+    Pb = P[0, bi.item()].cpu().numpy().reshape(3, 4).astype(np.float64)
+    Kinv = np.array([[1 / K4[0], 0, -K4[2] / K4[0]], [0, 1 / K4[1], -K4[3] / K4[1]], [0, 0, 1]])
+    Rt = Kinv @ Pb
+    assert np.abs(Rt[:, :3] - R).max() < 2e-3 and np.abs(Rt[:, 3] - t).max() < 2e-2
+    assert cnt[0, :8].sum().item() == 0
