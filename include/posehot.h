@@ -221,6 +221,27 @@ int ph_refine_pose_lm(const float* obj, const float* img, const int32_t* n_valid
                       const double* K4, const double* dist5, int max_iters,
                       double* pose, double* rms, int32_t* iters, void* stream);
 
+/* The same refinement for the RANSAC path: points as SoA rows X, Y, Z, u, v [B][N] f32 (as ph_score_pnp takes
+ * them; (u, v) distorted pixels under K4/dist5 — pass dist5 = 0 for undistorted pixels, K4 = (1,1,0,0) for
+ * normalised coordinates) and an optional inlier mask [B][ceil(N/64)] (ph_inlier_mask_pnp): only points whose
+ * bit is set enter the cost (NULL = all n_valid[b] points).  rms is over the points used. */
+int ph_refine_pose_lm_soa(const float* X, const float* Y, const float* Z, const float* u, const float* v,
+                          const uint64_t* mask, const int32_t* n_valid, int B, int N,
+                          const double* K4, const double* dist5, int max_iters,
+                          double* pose, double* rms, int32_t* iters, void* stream);
+
+/* (rvec, tvec) [B][6] f64 of hypothesis sel[b] (NULL = 0) of item b's [H][12] f32 block of 3x4 matrices
+ * K [R|t] (K4 given) or [R|t] (K4 NULL): the initial pose ph_refine_pose_lm* starts from after ph_select_best.
+ * No reference counterpart (glue between north_star's RANSAC and main.py:101-104's refinement). */
+int ph_pose_from_projection(const float* P, const int32_t* sel, int H, int B, const double* K4,
+                            double* pose, void* stream);
+
+/* get_camera_position_and_orientation, main.py:112-143, batched: pose [B][6] f64 (rvec, tvec) ->
+ * camera [B][22] f64 = position -R't (3) | forward R'[0,0,1]' (3, main.py:132) | up R'[0,-1,0]' (3,
+ * main.py:135) | R_cam_to_world row-major (9) | quaternion [w, x, y, z] (4, main.py:138-141: SciPy's
+ * from_matrix().as_quat() re-ordered, no sign canonicalisation). */
+int ph_camera_from_pose(const double* pose, int B, double* camera, void* stream);
+
 /* Inverse of the distortion model for 2-D points (pixels [n][2] f32 -> normalised, undistorted
  * [n][2] f32), `iters` fixed-point iterations in float64: the one-off undistort ahead of
  * ph_score_pnp / ph_score_essential. */

@@ -253,6 +253,20 @@ def get_camera_position_and_orientation(rvec, tvec):
     return camera_position.flatten(), camera_forward.flatten(), camera_up.flatten(), R_cam_to_world, quaternion_wxyz
 
 
+def camera_from_pose_batched(pose):
+    """get_camera_position_and_orientation (main.py:112-143) for B poses in one launch.
+
+    pose [B,6] f64 on the GPU -> dict of device tensors: position [B,3], forward [B,3], up [B,3],
+    R_cam_to_world [B,3,3], quaternion [B,4] in [w,x,y,z] order."""
+    lib = L.load()
+    pose = L.dev(pose, torch.float64, "pose")
+    B = pose.shape[0]
+    out = torch.empty((B, 22), dtype=torch.float64, device=pose.device)
+    L.check(lib.ph_camera_from_pose(L.ptr(pose), B, L.ptr(out), L.stream_ptr()), "ph_camera_from_pose")
+    return dict(position=out[:, 0:3], forward=out[:, 3:6], up=out[:, 6:9], R_cam_to_world=out[:, 9:18].reshape(B, 3, 3),
+                quaternion=out[:, 18:22])
+
+
 # ----------------------------------------------------------------------------- solvePnP(ITERATIVE), planar
 def _undistort_np(uv, K, dist, iters=20):
     k1, k2, p1, p2, k3 = dist

@@ -180,7 +180,7 @@ __device__ void log_so3(const double (&R)[9], double* w) {
 }
 
 // residual (ru, rv) of one point and, optionally, its 2x6 Jacobian w.r.t. (dw, dt)
-__device__ __forceinline__ void lm_point(const double (&R)[9], const double* t, const Cam& cam, const float* X3, const float* m2,
+__device__ __forceinline__ void lm_point(const double (&R)[9], const double* t, const Cam& cam, const float (&X3)[3], const float (&m2)[2],
                                          double& ru, double& rv, double (*J)[6]) {
     const double X = X3[0], Y = X3[1], Z = X3[2];
     const double rx = R[0] * X + R[1] * Y + R[2] * Z, ry = R[3] * X + R[4] * Y + R[5] * Z, rz = R[6] * X + R[7] * Y + R[8] * Z;
@@ -219,20 +219,40 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restrict__ obj, const float* __restrict__ img,
-                                                         const int32_t* __restrict__ n_valid, int N,
-                                                         const double* __restrict__ K4, const double* __restrict__ d5,
-                                                         int max_iters, double* __restrict__ pose, double* __restrict__ rms,
-                                                         int32_t* __restrict__ iters_out) {
-    __shared__ double red[4][28];
+// Point sources of the refinement kernel: the board path hands over interleaved rows (obj [B][N][3], img [B][N][2]),
+// the RANSAC path SoA rows [B][N] plus the winning hypothesis' inlier mask.
+struct PointsAoS {
+    const float* obj; const float* img;
+    __device__ __forceinline__ bool get(int b, int N, int i, float (&X3)[3], float (&m2)[2]) const {
+        const float* o = obj + ((size_t)b * N + i) * 3;
+        const float* m = img + ((size_t)b * N + i) * 2;
+        X3[0] = o[0]; X3[1] = o[1]; X3[2] = o[2]; m2[0] = m[0]; m2[1] = m[1];
+        return true;
+    }
+};
+struct PointsSoA {
+    const float *X, *Y, *Z, *u, *v; const uint64_t* mask; int words;
+    __device__ __forceinline__ bool get(int b, int N, int i, float (&X3)[3], float (&m2)[2]) const {
+        if (mask && !((mask[(size_t)b * words + (i >> 6)] >> (i & 63)) & 1ull)) return false;
+        const size_t o = (size_t)b * N + i;
+        X3[0] = X[o]; X3[1] = Y[o]; X3[2] = Z[o]; m2[0] = u[o]; m2[1] = v[o];
+        return true;
+    }
+};
+
+template <class Pts, int NT>
+__global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const int32_t* __restrict__ n_valid, int N,
+                                                        const double* __restrict__ K4, const double* __restrict__ d5,
+                                                        int max_iters, double* __restrict__ pose, double* __restrict__ rms,
+                                                        int32_t* __restrict__ iters_out) {
+    constexpr int NW = NT / 64;
+    __shared__ double red[NW][28];
     __shared__ double sh_R[9], sh_t[3], sh_Rc[9], sh_tc[3];
     __shared__ double sh_cost;
     __shared__ int sh_flag;                      // 0 continue, 1 converged/stop
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
     const Cam cam = load_cam(K4, d5);
-    const float* O = obj + (size_t)b * N * 3;
-    const float* M = img + (size_t)b * N * 2;
     double* P = pose + (size_t)b * 6;
 
     if (tid == 0) {
@@ -257,9 +277,11 @@ __global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restric
         double acc[28];
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-        for (int i = tid; i < nv; i += 256) {
+        for (int i = tid; i < nv; i += NT) {
             double ru, rv, J[2][6];
-            lm_point(R, t, cam, O + 3 * i, M + 2 * i, ru, rv, J);
+            float X3[3], m2[2];
+            if (!pts.get(b, N, i, X3, m2)) continue;
+            lm_point(R, t, cam, X3, m2, ru, rv, J);
             int q = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -277,7 +299,7 @@ __global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restric
         __syncthreads();
         if (tid == 0) {
             double s[28];
-            for (int k = 0; k < 28; ++k) s[k] = red[0][k] + red[1][k] + red[2][k] + red[3][k];
+            for (int k = 0; k < 28; ++k) { s[k] = 0.0; for (int w = 0; w < NW; ++w) s[k] += red[w][k]; }
             cost = s[27];
             sh_cost = cost;
             // damped system (Marquardt scaling), Cholesky
@@ -319,15 +341,18 @@ __global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 3; ++k) tc[k] = sh_tc[k];
         double c2 = 0.0;
-        for (int i = tid; i < nv; i += 256) {
+        for (int i = tid; i < nv; i += NT) {
             double ru, rv;
-            lm_point(Rc, tc, cam, O + 3 * i, M + 2 * i, ru, rv, nullptr);
+            float X3[3], m2[2];
+            if (!pts.get(b, N, i, X3, m2)) continue;
+            lm_point(Rc, tc, cam, X3, m2, ru, rv, nullptr);
             c2 += ru * ru + rv * rv;
         }
         c2 = wave_sum(c2);
         if (lane == 0) red[wave][0] = c2;
         __syncthreads();
-        const double cnew = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        double cnew = 0.0;
+        for (int w = 0; w < NW; ++w) cnew += red[w][0];
         const double cold = sh_cost;
         const int flag = sh_flag;
         __syncthreads();
@@ -347,22 +372,28 @@ __global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restric
         __syncthreads();
     }
     // ---- cost at the pose that is returned (also covers max_iters == 0 and early stops)
+    double n_used = 0.0;
     {
         double R[9], t[3];
 #pragma unroll
         for (int k = 0; k < 9; ++k) R[k] = sh_R[k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) t[k] = sh_t[k];
-        double c2 = 0.0;
-        for (int i = tid; i < nv; i += 256) {
+        double c2 = 0.0, cnt = 0.0;
+        for (int i = tid; i < nv; i += NT) {
             double ru, rv;
-            lm_point(R, t, cam, O + 3 * i, M + 2 * i, ru, rv, nullptr);
+            float X3[3], m2[2];
+            if (!pts.get(b, N, i, X3, m2)) continue;
+            lm_point(R, t, cam, X3, m2, ru, rv, nullptr);
             c2 += ru * ru + rv * rv;
+            cnt += 1.0;
         }
         c2 = wave_sum(c2);
-        if (lane == 0) red[wave][0] = c2;
+        cnt = wave_sum(cnt);
+        if (lane == 0) { red[wave][0] = c2; red[wave][1] = cnt; }
         __syncthreads();
-        cost = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        cost = 0.0; n_used = 0.0;
+        for (int w = 0; w < NW; ++w) { cost += red[w][0]; n_used += red[w][1]; }
     }
     if (tid == 0) {
         if (it > 0) {                               // no iteration ran: the caller's pose stays bit-for-bit
@@ -371,9 +402,90 @@ __global__ __launch_bounds__(256) void refine_pose_kernel(const float* __restric
             log_so3(R, w);
             P[0] = w[0]; P[1] = w[1]; P[2] = w[2]; P[3] = sh_t[0]; P[4] = sh_t[1]; P[5] = sh_t[2];
         }
-        if (rms) rms[b] = nv > 0 ? sqrt(cost / nv) : 0.0;
+        if (rms) rms[b] = n_used > 0.0 ? sqrt(cost / n_used) : 0.0;
         if (iters_out) iters_out[b] = it;
     }
+}
+
+// Winning 3x4 hypothesis -> (rvec, tvec): undo K when given, project the 3x3 block onto SO(3) (one Newton step of the
+// polar decomposition is enough for a matrix that is a rotation up to f32 rounding), Rodrigues vector.
+__global__ __launch_bounds__(64) void pose_from_projection_kernel(const float* __restrict__ P, const int32_t* __restrict__ sel,
+                                                                 int H, int B, const double* __restrict__ K4,
+                                                                 double* __restrict__ pose) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int h = sel ? min(max(sel[b], 0), H - 1) : 0;
+    const float* p = P + ((size_t)b * H + h) * 12;
+    double M[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) M[r][c] = (double)p[4 * r + c];
+    if (K4) {
+        const double fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            M[0][c] = (M[0][c] - cx * M[2][c]) / fx;
+            M[1][c] = (M[1][c] - cy * M[2][c]) / fy;
+        }
+    }
+    double R[9] = {M[0][0], M[0][1], M[0][2], M[1][0], M[1][1], M[1][2], M[2][0], M[2][1], M[2][2]};
+    // R <- R (3 I - R'R) / 2   (Newton-Schulz step towards the nearest orthogonal matrix)
+    double G[9], Rn[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            G[3 * i + j] = (i == j ? 3.0 : 0.0) - (R[i] * R[j] + R[3 + i] * R[3 + j] + R[6 + i] * R[6 + j]);
+    mat3_mul(R, G, Rn);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rn[k] *= 0.5;
+    double w[3];
+    log_so3(Rn, w);
+    double* o = pose + (size_t)b * 6;
+    o[0] = w[0]; o[1] = w[1]; o[2] = w[2]; o[3] = M[0][3]; o[4] = M[1][3]; o[5] = M[2][3];
+}
+
+// get_camera_position_and_orientation (main.py:112-143), batched: per pose 22 doubles =
+// position (3) | forward (3) | up (3) | R_cam_to_world row-major (9) | quaternion w,x,y,z (4).
+// Quaternion: the algorithm of scipy Rotation.from_matrix(...).as_quat() for a proper rotation
+// (largest of the three diagonal entries and the trace picks the branch; no sign canonicalisation),
+// re-ordered to [w, x, y, z] as main.py:138-141 does.
+__global__ __launch_bounds__(64) void camera_from_pose_kernel(const double* __restrict__ pose, int B, double* __restrict__ out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const double* p = pose + (size_t)b * 6;
+    double R[9];
+    rodrigues(p, R);                                   // board -> camera
+    double* o = out + (size_t)b * 22;
+    const double t0 = p[3], t1 = p[4], t2 = p[5];
+    double C[9];                                       // camera -> world = R'
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[3 * i + j] = R[3 * j + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        o[i] = -(C[3 * i] * t0 + C[3 * i + 1] * t1 + C[3 * i + 2] * t2);    // -R' t        (main.py:126)
+        o[3 + i] = C[3 * i + 2];                                           // R' [0 0 1]'  (main.py:132)
+        o[6 + i] = -C[3 * i + 1];                                          // R' [0 -1 0]' (main.py:135)
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[9 + k] = C[k];
+    const double d0 = C[0], d1 = C[4], d2 = C[8], tr = d0 + d1 + d2;
+    double q[4];                                       // x, y, z, w
+    if (tr > d0 && tr > d1 && tr > d2) {              // numpy argmax over (d0, d1, d2, tr): first maximum wins
+        q[0] = C[7] - C[5]; q[1] = C[2] - C[6]; q[2] = C[3] - C[1]; q[3] = 1.0 + tr;
+    } else {
+        const int i = (d0 >= d1 && d0 >= d2) ? 0 : (d1 >= d2 ? 1 : 2);
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        q[i] = 1.0 - tr + 2.0 * C[4 * i];
+        q[j] = C[3 * j + i] + C[3 * i + j];
+        q[k] = C[3 * k + i] + C[3 * i + k];
+        q[3] = C[3 * k + j] - C[3 * j + k];
+    }
+    const double inv = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    o[18] = q[3] * inv; o[19] = q[0] * inv; o[20] = q[1] * inv; o[21] = q[2] * inv;
 }
 
 }  // namespace
@@ -416,7 +528,47 @@ extern "C" int ph_refine_pose_lm(const float* obj, const float* img, const int32
     if (B < 0 || N < 0 || max_iters < 0) return PH_ERR_INVALID_ARG;
     if (B == 0) return PH_OK;
     if (!pose || !K4 || !dist5 || (N > 0 && (!obj || !img))) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(refine_pose_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, obj, img, n_valid, N, K4, dist5,
-                       max_iters, pose, rms, iters);
+    const PointsAoS pts{obj, img};
+    if (N <= 2048)
+        hipLaunchKernelGGL((refine_pose_kernel<PointsAoS, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, pts, n_valid, N,
+                           K4, dist5, max_iters, pose, rms, iters);
+    else
+        hipLaunchKernelGGL((refine_pose_kernel<PointsAoS, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, pts, n_valid,
+                           N, K4, dist5, max_iters, pose, rms, iters);
+    return ph_launch_status();
+}
+
+extern "C" int ph_refine_pose_lm_soa(const float* X, const float* Y, const float* Z, const float* u, const float* v,
+                                     const uint64_t* mask, const int32_t* n_valid, int B, int N, const double* K4,
+                                     const double* dist5, int max_iters, double* pose, double* rms, int32_t* iters,
+                                     void* stream) {
+    if (B < 0 || N < 0 || max_iters < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!pose || !K4 || !dist5 || (N > 0 && (!X || !Y || !Z || !u || !v))) return PH_ERR_INVALID_ARG;
+    const PointsSoA pts{X, Y, Z, u, v, mask, (N + 63) / 64};
+    if (N <= 2048)
+        hipLaunchKernelGGL((refine_pose_kernel<PointsSoA, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, pts, n_valid, N,
+                           K4, dist5, max_iters, pose, rms, iters);
+    else
+        hipLaunchKernelGGL((refine_pose_kernel<PointsSoA, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, pts, n_valid,
+                           N, K4, dist5, max_iters, pose, rms, iters);
+    return ph_launch_status();
+}
+
+extern "C" int ph_pose_from_projection(const float* P, const int32_t* sel, int H, int B, const double* K4, double* pose,
+                                       void* stream) {
+    if (B < 0 || H < 1) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!P || !pose) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pose_from_projection_kernel, dim3(ph_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, P, sel, H, B,
+                       K4, pose);
+    return ph_launch_status();
+}
+
+extern "C" int ph_camera_from_pose(const double* pose, int B, double* camera, void* stream) {
+    if (B < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!pose || !camera) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(camera_from_pose_kernel, dim3(ph_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, pose, B, camera);
     return ph_launch_status();
 }

@@ -107,3 +107,33 @@ def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     best_count, mask, E_hyp, front, win and, with want_points, xyz / pts)."""
     return relative_pose_back(relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio,
                                                   want_points, n_samples, seed))
+
+
+def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096, seed=0, refine=True, max_iters=20):
+    """RANSAC absolute pose (PnP) of B frames from 2-D/3-D correspondences, all on the device (SURVEY.md §8d cfg 5):
+
+        Philox 3-point samples -> P3P (4 hypothesis slots per sample) -> score H = 4*n_samples hypotheses
+          -> best hypothesis -> inlier mask -> Levenberg-Marquardt on the inliers (the reference's solver
+          semantics, main.py:101-104) -> final inlier count.
+
+    X, Y, Z, u, v: float32 ``[B, N]`` SoA rows, (u, v) undistorted pixels; K4 = (fx, fy, cx, cy) float64 device
+    tensor.  Returns dict(pose [B,6] f64 (rvec, tvec), pose0 (the winning minimal hypothesis), best_count,
+    best_idx, count [B,H], mask, rms, iters, P_hyp)."""
+    fx, fy, cx, cy = (K4[k].to(torch.float32) for k in range(4))
+    xn, yn = (u - cx) / fx, (v - cy) / fy
+    B, N = X.shape
+    thr_sq = float(thr_px) ** 2
+    samples = ransac.sample_minimal(seed, n_valid, N, n_samples, m=3) if n_valid is not None else \
+        ransac.sample_minimal(seed, torch.full((B,), N, dtype=torch.int32, device=X.device), N, n_samples, m=3)
+    P = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4)
+    cnt = ransac.score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid)
+    bi, bc = ransac.select_best(cnt)
+    mask = ransac.inlier_mask_pnp(P, bi, X, Y, Z, u, v, thr_sq, n_valid)
+    pose0 = ransac.pose_from_projection(P, bi, K4)
+    out = dict(pose0=pose0, best_count=bc, best_idx=bi, mask=mask, P_hyp=P, count=cnt)
+    if refine:
+        pose, rms, iters = ransac.refine_pose_lm_soa(X, Y, Z, u, v, pose0, K4, None, mask, n_valid, max_iters)
+        out.update(pose=pose, rms=rms, iters=iters)
+    else:
+        out.update(pose=pose0)
+    return out

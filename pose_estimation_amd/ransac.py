@@ -76,6 +76,44 @@ def solve_p3p(X, Y, Z, u, v, samples, K4=None, want_counts=False):
     return (P, ns) if want_counts else P
 
 
+def pose_from_projection(P, sel=None, K4=None):
+    """(rvec, tvec) float64 ``[B, 6]`` of hypothesis sel[b] of each item's ``[H, 12]`` block (K [R|t] when K4 is given)."""
+    lib = L.load()
+    P = L.dev(P, torch.float32, "P")
+    if P.dim() != 3 or P.shape[2] != 12:
+        raise ValueError("P must be [B, H, 12]")
+    B, H = P.shape[0], P.shape[1]
+    sel = L.opt_i32(sel, B, "sel")
+    if K4 is not None:
+        K4 = L.dev(K4, torch.float64, "K4")
+    pose = torch.empty((B, 6), dtype=torch.float64, device=P.device)
+    L.check(lib.ph_pose_from_projection(L.ptr(P), L.ptr(sel), H, B, L.ptr(K4), L.ptr(pose), L.stream_ptr()),
+            "ph_pose_from_projection")
+    return pose
+
+
+def refine_pose_lm_soa(X, Y, Z, u, v, pose, K4, dist5=None, mask=None, n_valid=None, max_iters=30):
+    """Levenberg-Marquardt on the reprojection error over the masked points (float64, one block per item).
+    Returns (pose ``[B, 6]``, rms ``[B]``, iters ``[B]``); the input pose tensor is not modified."""
+    lib = L.load()
+    X, Y, Z, u, v = _pts((X, Y, Z, u, v), ("X", "Y", "Z", "u", "v"))
+    B, N = X.shape
+    pose = L.dev(pose, torch.float64, "pose").clone()
+    K4 = L.dev(K4, torch.float64, "K4")
+    dist5 = torch.zeros(5, dtype=torch.float64, device=X.device) if dist5 is None else L.dev(dist5, torch.float64, "dist5")
+    if mask is not None:
+        mask = L.dev(mask, torch.int64, "mask")
+        if mask.shape != (B, (N + 63) // 64):
+            raise ValueError("mask must be [B, ceil(N/64)] 64-bit words")
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    rms = torch.empty((B,), dtype=torch.float64, device=X.device)
+    iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+    L.check(lib.ph_refine_pose_lm_soa(L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(mask), L.ptr(n_valid), B, N,
+                                      L.ptr(K4), L.ptr(dist5), int(max_iters), L.ptr(pose), L.ptr(rms), L.ptr(iters),
+                                      L.stream_ptr()), "ph_refine_pose_lm_soa")
+    return pose, rms, iters
+
+
 def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None):
     """Inlier count of every E hypothesis (Sampson error < thr).  Returns int32 ``[B, H]``."""
     lib = L.load()

@@ -1,0 +1,81 @@
+"""PnP RANSAC pipeline on the device (SURVEY.md §8d cfg 5, §8f items 1-2) and the camera-inversion epilogue.
+
+Bars: hypothesis counts / winner / mask bit-exact against the oracle's scoring of the same hypotheses; the
+minimal-hypothesis pose read back from the winning 3x4 matrix equals it to f32 rounding; the refined pose equals the
+oracle's NumPy LM on the same inlier set (pose 1e-6, rms 1e-7 px) and recovers the ground truth; the batched
+camera inversion equals the reference-named host function and the SciPy-pinned quaternion goldens to 1e-12.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from pose_estimation_amd import board, geometry, pipeline, ransac, synthetic
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def test_absolute_pose_pipeline(device):
+    B, N, S = 4, 4096, 256
+    fr = synthetic.pnp_frames(B, N, outliers=0.3, noise_px=1.0, seed=55)
+    n_valid = np.array([N, N - 100, 2000, N], np.int32)
+    pts = [_t(fr[k], device) for k in "XYZuv"]
+    K4 = _t(orc.K4, device)
+    out = pipeline.absolute_pose_batch(*pts, K4, thr_px=8.0, n_valid=_t(n_valid, device), n_samples=S, seed=3, max_iters=30)
+    P = out["P_hyp"].cpu().numpy()
+    cnt, bi, bc = out["count"].cpu().numpy(), out["best_idx"].cpu().numpy(), out["best_count"].cpu().numpy()
+    mask = out["mask"].cpu().numpy().view(np.uint64)
+    pose0, pose, rms = out["pose0"].cpu().numpy(), out["pose"].cpu().numpy(), out["rms"].cpu().numpy()
+    K = np.array([[orc.K4[0], 0, orc.K4[2]], [0, orc.K4[1], orc.K4[3]], [0, 0, 1.0]])
+    for b in range(B):
+        nv = int(n_valid[b])
+        a = [fr[k][b, :nv] for k in "XYZuv"]
+        rc = orc.score_pnp(P[b], *a, 64.0)
+        assert np.array_equal(rc, cnt[b])
+        rbi, rbc = orc.select_best(rc)
+        assert (rbi, rbc) == (bi[b], bc[b])
+        rmask = orc.inlier_mask_pnp(P[b, bi[b]], *a, 64.0, N)
+        assert np.array_equal(rmask, mask[b])
+        inl = orc.unpack_mask(mask[b], N)[:nv]
+        assert inl.sum() == bc[b] and bc[b] > 0.6 * nv
+        # winning hypothesis -> (rvec, tvec)
+        Rt = np.linalg.inv(K) @ P[b, bi[b]].reshape(3, 4).astype(np.float64)
+        assert np.abs(board.rodrigues(pose0[b, :3]) - Rt[:, :3]).max() < 1e-6     # f32 storage of K [R|t]
+        assert np.abs(pose0[b, 3:] - Rt[:, 3]).max() < 1e-5
+        # refinement on the inliers == NumPy LM on the same set, and close to the truth
+        obj = np.stack([a[0], a[1], a[2]], axis=1)[inl]; img = np.stack([a[3], a[4]], axis=1)[inl]
+        rp, rrms = orc.refine_pose_lm_np(obj, img, pose0[b], dist=np.zeros(5), max_iters=100)
+        assert geometry.rotation_angle_deg(board.rodrigues(pose[b, :3]), board.rodrigues(rp[:3])) < 1e-4
+        assert np.abs(pose[b, 3:] - rp[3:]).max() < 1e-6 and abs(rms[b] - rrms) < 1e-7
+        assert geometry.rotation_angle_deg(board.rodrigues(pose[b, :3]), fr["R"][b]) < 0.05
+        assert np.linalg.norm(pose[b, 3:] - fr["t"][b]) < 5e-3
+        assert rms[b] < 8.0
+
+
+def test_camera_from_pose_matches_reference_function_and_goldens(device):
+    d = json.load(open(os.path.join(G, "quaternions.json")))
+    poses, quats, Rs = [], [], []
+    for c in d["cases"]:
+        Rcw = np.array(c["R"])
+        poses.append(np.concatenate([board.rotation_to_rvec(Rcw.T), [0.1, -0.2, 0.7]]))
+        quats.append(np.array(c["quat_xyzw"])); Rs.append(Rcw)
+    poses = np.stack(poses)
+    cam = board.camera_from_pose_batched(_t(poses, device))
+    cam = {k: v.cpu().numpy() for k, v in cam.items()}
+    for b in range(len(poses)):
+        pos, fwd, up, Rm, q = board.get_camera_position_and_orientation(poses[b, :3], poses[b, 3:])
+        assert np.abs(cam["position"][b] - pos).max() < 1e-12 and np.abs(cam["forward"][b] - fwd).max() < 1e-12
+        assert np.abs(cam["up"][b] - up).max() < 1e-12 and np.abs(cam["R_cam_to_world"][b] - Rm).max() < 1e-12
+        # against the goldens through a host rvec round trip, which costs digits for angles next to pi
+        assert np.abs(cam["R_cam_to_world"][b] - Rs[b]).max() < 1e-7
+        g = quats[b][[3, 0, 1, 2]]
+        assert min(np.abs(cam["quaternion"][b] - g).max(), np.abs(cam["quaternion"][b] + g).max()) < 1e-7
+        assert min(np.abs(cam["quaternion"][b] - q).max(), np.abs(cam["quaternion"][b] + q).max()) < 1e-9
