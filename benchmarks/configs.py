@@ -3,6 +3,7 @@
 
     python benchmarks/configs.py --cfg 3            # 100-camera ring, 4,950 pairs, 32k binary descriptors
     python benchmarks/configs.py --cfg 4 --pairs N  # 1,000 views, 8k binary descriptors, first N of 499,500 pairs
+    python benchmarks/configs.py --cfg 5            # 32 frames x 65,536 2-D/3-D correspondences, 16,384 P3P hypotheses
 
 Prints one JSON line: pairs/s over the whole pair list (views resident, pairs in chunks, the front of chunk
 k+1 enqueued before the host finishes chunk k) and the accuracy against the synthetic ground truth.
@@ -20,6 +21,45 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pose_estimation_amd import geometry, matching, pipeline, sharding, synthetic  # noqa: E402
 
 
+def cfg5(args, dev):
+    """PnP stress (SURVEY.md §8d cfg 5): per frame 4096 Philox 3-point samples -> P3P (4 slots each = 16,384
+    hypotheses) -> scoring at `thr` px -> winner -> mask -> LM on the inliers.  One JSON line per threshold."""
+    from pose_estimation_amd import board, ransac
+    B, N, S = args.frames, args.feat or 65536, args.samples if args.samples != 410 else 4096
+    t0 = time.perf_counter()
+    fr = synthetic.pnp_frames(B, N, outliers=0.3, noise_px=1.0, seed=1005)
+    gen_s = time.perf_counter() - t0
+    pts = [torch.from_numpy(fr[k]).to(dev) for k in "XYZuv"]
+    K4 = torch.tensor([synthetic.FX, synthetic.FY, synthetic.CX, synthetic.CY], dtype=torch.float64, device=dev)
+    for thr in (8.0, 2.0):
+        run = lambda seed: pipeline.absolute_pose_batch(*pts, K4, thr_px=thr, n_samples=S, seed=seed, max_iters=20)
+        run(0); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+        ev[0].record()
+        for k in range(args.iters):
+            out = run(k + 1)
+            ev[k + 1].record()
+        torch.cuda.synchronize()
+        ms = np.array([ev[k].elapsed_time(ev[k + 1]) for k in range(args.iters)])
+        # scoring alone, same hypotheses (the kernel SURVEY.md §8d prices): HIP events around the launch
+        P = out["P_hyp"]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); ransac.score_pnp(P, *pts, thr * thr); e1.record(); torch.cuda.synchronize()
+        pose = out["pose"].cpu().numpy()
+        rerr = np.array([geometry.rotation_angle_deg(board.rodrigues(pose[b, :3]), fr["R"][b]) for b in range(B)])
+        terr = np.array([np.linalg.norm(pose[b, 3:] - fr["t"][b]) for b in range(B)])
+        bc = out["best_count"].cpu().numpy()
+        print(json.dumps({"cfg": 5, "frames": B, "correspondences": N, "hypotheses": 4 * S, "threshold_px": thr,
+                          "ms_per_batch": float(np.median(ms)), "frames_per_s": B / (np.median(ms) * 1e-3),
+                          "hyps_per_s": B * 4 * S / (np.median(ms) * 1e-3), "score_kernel_ms": e0.elapsed_time(e1),
+                          "score_only_hyps_per_s": B * 4 * S / (e0.elapsed_time(e1) * 1e-3),
+                          "scene_generation_s": gen_s, "median_inliers": float(np.median(bc)),
+                          "true_inliers": float(fr["inlier_truth"].sum(1).mean()),
+                          "rot_err_deg": {"median": float(np.median(rerr)), "max": float(rerr.max())},
+                          "t_err_m": {"median": float(np.median(terr)), "max": float(terr.max())},
+                          "rms_px": float(out["rms"].median().item()), "lm_iters": int(out["iters"].max().item())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cfg", type=int, default=3)
@@ -28,7 +68,13 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="limit the pair list (0 = all)")
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--samples", type=int, default=410)
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
+    if args.cfg == 5:
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        return cfg5(args, dev)
     V = args.views or (100 if args.cfg == 3 else 1000)
     n = args.feat or (32768 if args.cfg == 3 else 8192)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
