@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 from pose_estimation_amd import matching, pipeline, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 SIMDs x 32768 FLOP / 32 cyc x 2.4 GHz
 N_FEAT, DIM = 8192, 128
 N_SAMPLES = 410                 # minimal samples per pair; the 5-point solver fills 10 hypothesis slots each
 N_HYP = 10 * N_SAMPLES          # 4100 essential-matrix hypotheses scored per pair (>= the 4096 of configs[1])
@@ -79,6 +80,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=16, help="pairs per step per GPU")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--precision", type=int, default=1,
+                    help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
+                         "1 = bf16x3 MFMA candidate filter + exact f32 re-rank")
     ap.add_argument("--check", action="store_true", help="verify pose accuracy of the last step against ground truth")
     args = ap.parse_args()
 
@@ -108,7 +112,7 @@ def main():
         k = state["step"]
         if k >= 0:
             ev[k][0].record()
-        r = matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq, norm_t=nt)
+        r = matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq, norm_t=nt, precision=args.precision)
         if k >= 0:
             ev[k][1].record()
         return (*r, "l2")
@@ -168,12 +172,27 @@ def main():
             print(f"# pair {p}: matches {int(tab[p,13])} inliers {int(tab[p,12])} rot err {ra:.4f} deg, t dir err {ta:.4f} deg",
                   file=sys.stderr)
 
+    if args.precision == 0:
+        roofline = {"kernel": "l2_top2_f32_kernel<128>", "bound": "mfma", "achieved": achieved,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": None, "launch_ms": kern_ms, "algorithmic_flops_per_launch": flops}
+    else:
+        # One ph_match_l2_top2 call = l2_filter_prep_kernel + l2_filter_kernel<4> + l2_rerank_kernel; the events bracket
+        # the call.  `achieved` counts the ALGORITHMIC 2*N*M*D flops per pair; the filter executes 3 bf16 MFMA products
+        # per algorithmic product (+3 % priming), so its ceiling on this scale is a third of the bf16 peak.
+        roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
+                    "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "launch_ms": kern_ms,
+                    "algorithmic_flops_per_launch": flops, "executed_bf16_mfma_flops_per_launch": flops * 3 * (1 + 8 / 256),
+                    "executed_frac_of_bf16_peak": achieved * 3 * (1 + 8 / 256) / PEAK_BF16_MFMA_TFLOPS,
+                    "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0, 81 % of the f32 MFMA peak)"}
     if rank == 0:
         res = {
             "metric": "image pairs/sec (relative pose, whole node) at 8k feats",
             "value": world * P * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "l2_precision": args.precision,
             "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
                                    "4096 essential-matrix hypotheses per pair", "pairs_per_step_per_gpu": P,
                        "features": N_FEAT, "dim": DIM, "hypotheses": N_HYP, "ratio": 0.75, "threshold_px": THR_PX,
@@ -181,10 +200,7 @@ def main():
                        "hypothesis_source": "generated in the timed region: Philox minimal samples of the pair's own matches -> device 5-point solver (10 slots per sample)",
                        "parallelism": f"pairs sharded over {world} rank(s), final all_gather of the [pairs,16] pose table"},
             "hyps_per_sec": world * P * N_HYP * args.steps / dt,
-            "roofline": {"kernel": "l2_top2_f32_kernel<128>", "bound": "mfma", "achieved": achieved,
-                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": None, "launch_ms": kern_ms,
-                         "algorithmic_flops_per_launch": flops},
+            "roofline": roofline,
         }
         if world == 1 and args.cpu_pairs > 0:
             threads = min(16, os.cpu_count() or 1)

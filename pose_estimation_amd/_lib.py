@@ -18,7 +18,7 @@ PH_OK = 0
 PH_NO_INDEX = -1
 PH_HAMMING_NONE = 0x7FFFFFFF
 PRECISION_F32 = 0
-PRECISION_BF16 = 1
+PRECISION_BF16X3_RERANK = 1
 
 
 class PosehotError(RuntimeError):
@@ -37,7 +37,7 @@ SIGNATURES = {
     "ph_status_string": (C.c_char_p, [_i]),
     "ph_match_hamming_ws_bytes": (_sz, [_i, _i, _i]),
     "ph_match_hamming_top2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
-    "ph_match_l2_ws_bytes": (_sz, [_i, _i, _i, _i]),
+    "ph_match_l2_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ph_row_sqnorm": (_i, [_p, _i64, _i, _p, _p]),
     "ph_match_l2_top2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "ph_ratio_filter_hamming": (_i, [_p, _p, _p, _i64, _f, _p, _p]),

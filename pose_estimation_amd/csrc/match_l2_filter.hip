@@ -1,0 +1,470 @@
+// match_l2_filter.hip — the squared-L2 matcher as "bf16x3 candidate filter + exact f32 re-rank".
+// Same contract and bit-identical outputs as the f32 MFMA kernel of match_l2.hip; the
+// matrix work runs on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) and only a handful of
+// candidates per query are re-evaluated with the contract's f32 fma chain.
+//
+// Filter.  Every f32 descriptor element x is split into two bf16 terms, x = xh + xl + xr with
+// |xr| <= 2^-16 |x|, and the score  s = q.t - |t|^2/2  is approximated by
+//     sA = -|t|^2/2 + sum_k (th*qh + tl*qh + th*ql)            (three bf16 MFMA products, f32 accumulate)
+// The dropped terms (tl*ql, tr*q, t*qr) are bounded by 3.1*2^-16 * sum|t_k||q_k|, the f32 accumulation of the
+// MFMAs and the rounding of the contract's own chain by a few 2^-20 of the same sum, so
+//     |sA - s| <= e_i := 2^-13 * (|q_i| * Tmax + Tmax^2 / 2),      Tmax = max_j |t_j|  of the pair's train view.
+// If a2 is ANY lower bound of the second-largest sA of the query (e.g. the second-largest seen so far by one
+// lane), both of the exact top-2 rows have sA >= a2 - 2 e_i: such rows are appended to a candidate list.  Every
+// (query, train split, lane half) owns a private list segment and counts in a register, so an append is one
+// fire-and-forget store: no atomics, nothing to wait for.  A short priming pass over the first tiles sets the bound before anything
+// is appended, so a query collects ~10 candidates out of 8192 rows.
+//
+// Re-rank.  l2_rerank_kernel evaluates the contract's exact chain (k order 8c+{0,4,1,5,2,6,3,7}, start
+// -|t|^2/2) for the listed rows, takes (max s, lowest index on ties) and the runner-up, and writes idx/d1sq/d2sq
+// exactly as the f32 kernel does.  A list that overflowed its capacity (adversarially ordered input) makes the
+// query fall back to the exact chain over ALL rows inside the same kernel: slower, never wrong.
+#include <math.h>
+
+#include "common.hpp"
+#include "match_l2_filter.hpp"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTR = 32;       // train rows per tile
+constexpr int kQT = 2;        // 32-query column tiles per wave
+constexpr int kDim = 128;
+constexpr int kCPR = kDim / 8;  // 16-byte bf16 chunks per row
+constexpr int kNS = kDim / 16;  // MFMA k-steps per row
+constexpr float kEpsScale = 1.0f / 8192.0f;   // 2^-13
+constexpr int kCapH = 32;      // list entries per (query, split, lane half)
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// 8 consecutive f32 -> 8 bf16 leading terms + 8 bf16 second terms (x - hi is exact in f32)
+__device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        h[p] = cvt_pk_bf16(x[2 * p], x[2 * p + 1]);
+        const float r0 = x[2 * p] - __uint_as_float(h[p] << 16);
+        const float r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
+        l[p] = cvt_pk_bf16(r0, r1);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// plain v_max_f32 (fmaxf would add a canonicalising v_max v,v,v per operand)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4 a, const uint4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// zero the per-query slot counters of the launch and compute Tmax per pair
+__global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __restrict__ tnorm, const int32_t* __restrict__ view_t,
+                                                            const int32_t* __restrict__ n_t, int nq, int nt, int slots,
+                                                            float* __restrict__ tmax, int32_t* __restrict__ cnt) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int vt = view_t ? view_t[b] : b;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const float* TN = tnorm + (size_t)vt * nt;
+    float m = 0.0f;
+    for (int j = tid; j < ntv; j += 256) m = fmaxf(m, TN[j]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    for (size_t i = tid; i < (size_t)nq * slots; i += 256) cnt[(size_t)b * nq * slots + i] = 0;
+    __syncthreads();
+    if (tid == 0) tmax[b] = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
+    const float* __restrict__ dq, const float* __restrict__ dt,
+    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
+    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
+    int nq, int nt, int rows_per_split,
+    const float* __restrict__ tnorm, const float* __restrict__ qnorm, const float* __restrict__ tmax,
+    int32_t* __restrict__ cnt, int32_t* __restrict__ list, int slots, int nqb, int B) {
+    constexpr int NT = WAVES * 64;
+    constexpr int STG = kTR * kCPR / NT;          // 8-float groups staged per thread per tile
+    __shared__ uint4 tile_hi[2][kTR * kCPR];
+    __shared__ uint4 tile_lo[2][kTR * kCPR];
+    __shared__ float4 tnl[2][kTR / 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    // Block -> (pair, split, query block).  Consecutive block ids go round-robin over the 8 XCDs, each with its own L2:
+    // all blocks of a pair are given ids of one residue mod 8, so a pair's train view is streamed through ONE L2.
+    const int per_pair = nqb * (slots / 2);
+    int b, rr;
+    if ((B & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        b = xcd + 8 * (i / per_pair); rr = i % per_pair;
+    } else {
+        b = blockIdx.x / per_pair; rr = blockIdx.x % per_pair;
+    }
+    const int split = rr / nqb, xb = rr % nqb;
+    const int vq = view_q ? view_q[b] : b;
+    const int vt = view_t ? view_t[b] : b;
+    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const float* Q = dq + (size_t)vq * nq * kDim;
+    const float4* T = (const float4*)(dt + (size_t)vt * nt * kDim);
+    const float* TN = tnorm + (size_t)vt * nt;
+    const float* QN = qnorm + (size_t)vq * nq;
+    const float Tm = tmax[b];
+
+    const int qw0 = xb * (NT / 64) * (32 * kQT) + wave * (32 * kQT);   // first query of this wave
+
+    // B fragments: query row (qw0 + ct*32 + li), elements 16s + 8h .. +7, split into two bf16 terms
+    uint4 bh[kQT][kNS], bl[kQT][kNS];
+    float thr[kQT], eps2[kQT], a1[kQT], a2[kQT];
+    size_t qoff[kQT];
+    int nc[kQT];                                     // entries in this lane's private list segment
+#pragma unroll
+    for (int ct = 0; ct < kQT; ++ct) {
+        const int qi = qw0 + ct * 32 + li;
+        const float4* qrow = (const float4*)(Q + (size_t)min(qi, nq - 1) * kDim);
+#pragma unroll
+        for (int s = 0; s < kNS; ++s) split8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], bh[ct][s], bl[ct][s]);
+        const bool live = qi < nqv;
+        qoff[ct] = ((size_t)b * nq + min(qi, nq - 1)) * slots + (2 * split + h);
+        nc[ct] = 0;
+        eps2[ct] = 2.0f * kEpsScale * (sqrtf(QN[min(qi, nq - 1)]) * Tm + 0.5f * Tm * Tm);
+        thr[ct] = live ? -3.0e38f : INFINITY;           // finite floor: the -inf score of a padded row never reaches it;
+                                                         // a dead lane never has a candidate
+        a1[ct] = -INFINITY; a2[ct] = -INFINITY;
+    }
+
+    const int t_begin = split * rows_per_split;
+    const int t_end = min(ntv, t_begin + rows_per_split);
+    if (t_begin >= t_end) return;
+    const int n_tiles = (t_end - t_begin + kTR - 1) / kTR;
+    const int n_prime = min(8, max(1, n_tiles / 16));
+
+    float4 stage[2 * STG];
+    float stage_tn = 0.0f;
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < STG; ++u) {
+            const int id = tid + NT * u, row = id / kCPR, p = id % kCPR;
+            const bool ok = t0 + row < t_end;
+            const float4* src = T + (size_t)(t0 + row) * (kDim / 4) + 2 * p;
+            stage[2 * u] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            stage[2 * u + 1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < kTR) stage_tn = (t0 + tid < t_end) ? -0.5f * TN[t0 + tid] : -INFINITY;
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < STG; ++u) {
+            const int id = tid + NT * u, row = id / kCPR, p = id % kCPR;
+            uint4 hi, lo;
+            split8(stage[2 * u], stage[2 * u + 1], hi, lo);
+            tile_hi[buf][row * kCPR + (p ^ (row & 15))] = hi;
+            tile_lo[buf][row * kCPR + (p ^ (row & 15))] = lo;
+        }
+        if (tid < kTR) ((float*)tnl[buf])[tid] = stage_tn;
+    };
+
+    auto tile_scores = [&](int buf, f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 z = tnl[buf][2 * g + h];      // rows 8g + 4h .. +3
+            acc0[4 * g + 0] = z.x; acc0[4 * g + 1] = z.y; acc0[4 * g + 2] = z.z; acc0[4 * g + 3] = z.w;
+        }
+        acc1 = acc0;
+        const uint4* rh = &tile_hi[buf][li * kCPR];
+        const uint4* rl = &tile_lo[buf][li * kCPR];
+#pragma unroll
+        for (int s = 0; s < kNS; ++s) {
+            const uint4 ah = rh[(2 * s + h) ^ (li & 15)];
+            const uint4 al = rl[(2 * s + h) ^ (li & 15)];
+            acc0 = mfma_bf16(ah, bh[0][s], acc0);
+            acc1 = mfma_bf16(ah, bh[1][s], acc1);
+            acc0 = mfma_bf16(al, bh[0][s], acc0);
+            acc1 = mfma_bf16(al, bh[1][s], acc1);
+            acc0 = mfma_bf16(ah, bl[0][s], acc0);
+            acc1 = mfma_bf16(ah, bl[1][s], acc1);
+        }
+    };
+
+    // priming: running top-2 of the approximate scores, nothing appended
+    auto prime = [&](const f32x16& acc, int ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r];
+            a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], v);
+            a1[ct] = fmaxf(a1[ct], v);
+        }
+    };
+    // filtering: rows whose approximate score reaches the bound are appended.  A max tree over the 16 accumulator
+    // registers is walked from the root; a subtree is entered only if some lane of the wave has a hit in it, so a
+    // tile with one hit costs ~9 wave-level tests instead of 16 masked blocks.  thr only rises while rows are appended,
+    // and every test uses the current value.
+    auto hit = [&](float v, int j, int ct) {
+        if (v >= thr[ct]) {
+            if (nc[ct] < kCapH) list[qoff[ct] * kCapH + nc[ct]] = j;
+            ++nc[ct];
+            a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], v);
+            a1[ct] = vmax(a1[ct], v);
+            thr[ct] = vmax(thr[ct], a2[ct] - eps2[ct]);
+        }
+    };
+    auto any_ge = [&](float m, int ct) { return __builtin_amdgcn_ballot_w64(m >= thr[ct]) != 0ull; };
+    auto filter = [&](const f32x16& acc, int ct, int t0) {
+        float m8[8], m4[4], m2[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m8[i] = vmax(acc[2 * i], acc[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m4[i] = vmax(m8[2 * i], m8[2 * i + 1]);
+        m2[0] = vmax(m4[0], m4[1]); m2[1] = vmax(m4[2], m4[3]);
+        if (!any_ge(vmax(m2[0], m2[1]), ct)) return;
+        const int jb = t0 + 4 * h;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            if (!any_ge(m2[g2], ct)) continue;
+#pragma unroll
+            for (int g4 = 2 * g2; g4 < 2 * g2 + 2; ++g4) {
+                if (!any_ge(m4[g4], ct)) continue;
+#pragma unroll
+                for (int g8 = 2 * g4; g8 < 2 * g4 + 2; ++g8) {
+                    if (!any_ge(m8[g8], ct)) continue;
+#pragma unroll
+                    for (int r = 2 * g8; r < 2 * g8 + 2; ++r) hit(acc[r], jb + (r & 3) + 8 * (r >> 2), ct);
+                }
+            }
+        }
+        thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
+    };
+
+    // Staging pipeline, one barrier per tile: at the top of iteration `it` tile `it` is in LDS buffer `cur` (written
+    // during the previous iteration) and the registers hold tile it+1.  After the barrier the registers are split and
+    // written into the other buffer and the loads of tile it+2 are issued — all of it next to this tile's MFMA chain.
+    const int n_iter = n_prime + n_tiles;
+    auto tile_row0 = [&](int it) { return t_begin + (it < n_prime ? it : it - n_prime) * kTR; };
+    fetch(tile_row0(0));
+    commit(0);
+    if (n_iter > 1) fetch(tile_row0(1));
+    int cur = 0;
+    for (int it = 0; it < n_iter; ++it) {
+        const bool priming = it < n_prime;
+        const int t0 = tile_row0(it);
+        __syncthreads();
+        if (it + 1 < n_iter) commit(cur ^ 1);
+        if (it + 2 < n_iter) fetch(tile_row0(it + 2));
+        f32x16 acc0, acc1;
+        tile_scores(cur, acc0, acc1);
+        if (priming) {
+            prime(acc0, 0);
+            prime(acc1, 1);
+            if (it + 1 == n_prime) {
+#pragma unroll
+                for (int ct = 0; ct < kQT; ++ct) {
+                    // second-largest of the union of the two halves' top-2, then restart the tracking: the primed
+                    // rows are seen again by the filtering pass
+                    const float o1 = __shfl_xor(a1[ct], 32), o2 = __shfl_xor(a2[ct], 32);
+                    const float second = fmaxf(fminf(a1[ct], o1), fmaxf(a2[ct], o2));
+                    thr[ct] = fmaxf(thr[ct], second - eps2[ct]);
+                    a1[ct] = -INFINITY; a2[ct] = -INFINITY;
+                }
+            }
+        } else {
+            filter(acc0, 0, t0);
+            filter(acc1, 1, t0);
+        }
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int ct = 0; ct < kQT; ++ct)
+        if (qw0 + ct * 32 + li < nqv) cnt[qoff[ct]] = nc[ct];
+}
+
+// exact contract chain: s = fma chain over k in the order 8c + {0,4,1,5,2,6,3,7}, started at -|t|^2/2
+__device__ __forceinline__ float exact_score(const float4* __restrict__ q, const float4* __restrict__ t, float tn) {
+    float acc = -0.5f * tn;
+#pragma unroll 8
+    for (int c = 0; c < kDim / 8; ++c) {
+        const float4 q0 = q[2 * c], q1 = q[2 * c + 1], t0 = t[2 * c], t1 = t[2 * c + 1];
+        acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
+        acc = ph_fma(t0.y, q0.y, acc); acc = ph_fma(t1.y, q1.y, acc);
+        acc = ph_fma(t0.z, q0.z, acc); acc = ph_fma(t1.z, q1.z, acc);
+        acc = ph_fma(t0.w, q0.w, acc); acc = ph_fma(t1.w, q1.w, acc);
+    }
+    return acc;
+}
+
+// Re-rank: 16 lanes per query (four queries per wave), one candidate row per lane and round.  A lane walking its
+// own 512-byte row would make every load instruction touch 64 different cache lines, so the rows are fetched
+// cooperatively instead — 16 consecutive lanes read one 256-byte half row — and transposed through LDS
+// (swizzled 16-byte chunks); each lane then reads its own row from LDS and runs the exact fma chain.
+constexpr int kRL = 16;
+__global__ __launch_bounds__(256) void l2_rerank_kernel(
+    const float* __restrict__ dq, const float* __restrict__ dt,
+    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
+    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t, int B, int nq, int nt,
+    const float* __restrict__ tnorm, const float* __restrict__ qnorm,
+    const int32_t* __restrict__ cnt, const int32_t* __restrict__ list, int slots,
+    int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq) {
+    __shared__ float4 rows[4][64 * 8];                     // per wave: 64 rows x 8 chunks (a 128-byte quarter row each)
+    // blocks of one pair share one residue of the block id mod 8 (one XCD, one L2 for the pair's train rows)
+    constexpr int QPB = 256 / kRL;
+    const int bpp = (nq + QPB - 1) / QPB;                 // blocks per pair
+    int b, bq;
+    if ((B & 7) == 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        b = xcd + 8 * (i / bpp); bq = i % bpp;
+    } else {
+        b = blockIdx.x / bpp; bq = blockIdx.x % bpp;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qi = bq * QPB + threadIdx.x / kRL;
+    const int sl = threadIdx.x % kRL;
+    const int vq = view_q ? view_q[b] : b;
+    const int vt = view_t ? view_t[b] : b;
+    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const bool live = qi < nqv;
+    const size_t o = (size_t)b * nq + min(qi, nq - 1);    // (pair, query) index
+    const float4* q = (const float4*)(dq + ((size_t)vq * nq + min(qi, nq - 1)) * kDim);
+    const float4* Tt = (const float4*)(dt + (size_t)vt * nt * kDim);
+    const float* TN = tnorm + (size_t)vt * nt;
+    float4* my = rows[wave];
+
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int32_t bi = PH_NO_INDEX;
+    auto keep = [&](float s, int j) {
+        const bool better = (s > m1) || (s == m1 && (bi < 0 || j < bi));
+        m2 = better ? m1 : fmaxf(m2, s);
+        bi = better ? j : bi;
+        m1 = better ? s : m1;
+    };
+
+    // this lane's entries: the query's list segments laid end to end, entry g = sl, sl + 16, ...
+    int total = 0;
+    bool overflow = false;
+    if (live)
+        for (int slot = 0; slot < slots; ++slot) {
+            const int c = cnt[o * slots + slot];
+            overflow |= c > kCapH;
+            total += min(c, kCapH);
+        }
+    if (overflow) total = 0;
+    int rounds = (total + kRL - 1) / kRL;
+    for (int w = 32; w > 0; w >>= 1) rounds = max(rounds, __shfl_xor(rounds, w));     // wave-uniform trip count
+    for (int rd = 0; rd < rounds; ++rd) {
+        const int g = rd * kRL + sl;
+        int j = -1;
+        if (g < total) {
+            int base = 0;
+            for (int slot = 0; slot < slots; ++slot) {
+                const int cc = min(cnt[o * slots + slot], kCapH);
+                if (g < base + cc) { j = list[(o * slots + slot) * kCapH + (g - base)]; break; }
+                base += cc;
+            }
+        }
+        float acc = (j >= 0) ? -0.5f * TN[j] : 0.0f;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            // cooperative fetch: in step i lanes 8g..8g+7 read the quarter row of the candidate held by lane 8i+g.
+            // The LDS region belongs to this wave alone and a wave's LDS operations complete in order, so only the
+            // compiler has to be kept from reordering across the transposition.
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * i + (lane >> 3);
+                const int jr = __shfl(j, r);
+                const int c = lane & 7;
+                if (jr >= 0) my[r * 8 + (c ^ (r & 7))] = Tt[(size_t)jr * (kDim / 4) + qt * 8 + c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (j >= 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 q0 = q[qt * 8 + 2 * c], q1 = q[qt * 8 + 2 * c + 1];
+                    const float4 t0 = my[lane * 8 + ((2 * c) ^ (lane & 7))], t1 = my[lane * 8 + ((2 * c + 1) ^ (lane & 7))];
+                    acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
+                    acc = ph_fma(t0.y, q0.y, acc); acc = ph_fma(t1.y, q1.y, acc);
+                    acc = ph_fma(t0.z, q0.z, acc); acc = ph_fma(t1.z, q1.z, acc);
+                    acc = ph_fma(t0.w, q0.w, acc); acc = ph_fma(t1.w, q1.w, acc);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (j >= 0) keep(acc, j);
+    }
+    if (overflow)                                          // a segment overflowed: exact scan of every row instead
+        for (int j = sl; j < ntv; j += kRL) keep(exact_score(q, Tt + (size_t)j * (kDim / 4), TN[j]), j);
+    // butterfly over the lanes of the query
+#pragma unroll
+    for (int w = kRL / 2; w > 0; w >>= 1) {
+        const float om1 = __shfl_xor(m1, w), om2 = __shfl_xor(m2, w);
+        const int32_t obi = __shfl_xor(bi, w);
+        const bool other = (obi >= 0) && ((om1 > m1) || (om1 == m1 && (bi < 0 || obi < bi)));
+        const float lost = other ? m1 : om1;
+        m2 = fmaxf(lost, fmaxf(m2, om2));
+        m1 = other ? om1 : m1;
+        bi = other ? obi : bi;
+    }
+    if (sl == 0 && qi < nq) {
+        if (!live) { idx[o] = PH_NO_INDEX; d1sq[o] = INFINITY; d2sq[o] = INFINITY; return; }
+        const float qn = qnorm[(size_t)vq * nq + qi];
+        idx[o] = bi;
+        d1sq[o] = (bi >= 0) ? fmaxf(0.0f, ph_fma(-2.0f, m1, qn)) : INFINITY;
+        d2sq[o] = (m2 > -INFINITY) ? fmaxf(0.0f, ph_fma(-2.0f, m2, qn)) : INFINITY;
+    }
+}
+
+constexpr int kWaves = 4;     // 256 queries per block
+
+}  // namespace
+
+L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
+    L2FilterPlan p;
+    const long blocks = (long)B * ph_ceil_div(nq, kWaves * 64);
+    int s = (int)((256 * (8 / kWaves) + blocks - 1) / blocks);   // 8 waves per CU
+    const int max_s = ph_ceil_div(nt, 32 * kTR);                // at least 32 tiles per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kTR) * kTR;
+    if (p.rows_per_split < kTR) p.rows_per_split = kTR;
+    p.splits = ph_ceil_div(nt, p.rows_per_split);
+    if (p.splits < 1) p.splits = 1;
+    p.slots = 2 * p.splits;
+    p.off_cnt = ((size_t)B * sizeof(float) + 255) / 256 * 256;
+    p.off_list = p.off_cnt + ((size_t)B * nq * p.slots * sizeof(int32_t) + 255) / 256 * 256;
+    p.total = p.off_list + (size_t)B * nq * p.slots * kCapH * sizeof(int32_t);
+    return p;
+}
+
+int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm_q, const float* norm_t,
+                     const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
+                     int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st) {
+    const L2FilterPlan p = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
+    float* tmax = (float*)ws;
+    int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
+    int32_t* list = (int32_t*)((char*)ws + p.off_list);
+    hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, view_t, n_t, nq, nt, p.slots, tmax, cnt);
+    if (nt > 0) {
+        const int nqb = ph_ceil_div(nq, kWaves * 64);
+        const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
+        hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, desc_t, view_q, view_t, n_q, n_t,
+                           nq, nt, p.rows_per_split, norm_t, norm_q, tmax, cnt, list, p.slots, nqb, B);
+    }
+    const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
+    hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                       view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, cnt, list, p.slots, idx, d1sq, d2sq);
+    return ph_launch_status();
+}

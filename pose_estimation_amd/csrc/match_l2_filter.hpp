@@ -1,0 +1,15 @@
+// Internal interface between match_l2.hip (C-ABI entry points) and match_l2_filter.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+struct L2FilterPlan {
+    int splits, rows_per_split, slots;
+    size_t off_cnt, off_list, total;   // workspace: Tmax[B] | entry counts [B][nq][slots] | candidate lists [B][nq][slots][32]; slots = 2 * splits
+};
+L2FilterPlan plan_l2_filter(int B, int nq, int nt);
+int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm_q, const float* norm_t,
+                     const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
+                     int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st);

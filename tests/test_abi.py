@@ -37,13 +37,15 @@ def test_argument_errors_without_gpu():
     assert lib.ph_match_hamming_top2(None, None, None, None, None, None, -1, 8, 8, 32, None, None, None, None, 0, None) == -1
     assert lib.ph_match_hamming_top2(None, None, None, None, None, None, 0, 8, 8, 32, None, None, None, None, 0, None) == 0
     assert lib.ph_match_l2_top2(None, None, None, None, None, None, None, None, 1, 8, 8, 96, 0, None, None, None, None, 0, None) == -2
-    assert lib.ph_match_l2_top2(None, None, None, None, None, None, None, None, 1, 8, 8, 128, 1, None, None, None, None, 0, None) == -2
+    assert lib.ph_match_l2_top2(None, None, None, None, None, None, None, None, 1, 8, 8, 128, 2, None, None, None, None, 0, None) == -2
+    assert lib.ph_match_l2_top2(None, None, None, None, None, None, None, None, 1, 8, 8, 128, 1, None, None, None, None, 0, None) == -1
     assert lib.ph_score_essential(None, None, None, None, None, None, 1, 4, 4, 1.0, None, None) == -1
     assert lib.ph_triangulate(None, None, None, None, None, None, None, None, 1, 1, 4, None, None, None) == -1
     assert lib.ph_select_best(None, 0, 4, None, None, None) == 0
     assert lib.ph_match_hamming_ws_bytes(1, 32768, 32768) > 0
     assert lib.ph_match_hamming_ws_bytes(4950, 32768, 32768) == 0
-    assert lib.ph_match_l2_ws_bytes(16, 8192, 8192, 128) == 0 and lib.ph_match_l2_ws_bytes(1, 8192, 8192, 128) > 0
+    assert lib.ph_match_l2_ws_bytes(16, 8192, 8192, 128, 0) == 0 and lib.ph_match_l2_ws_bytes(1, 8192, 8192, 128, 0) > 0
+    assert lib.ph_match_l2_ws_bytes(16, 8192, 8192, 128, 1) >= 16 * 8192 * 33 * 4
 
 
 def test_product_never_imports_oracle():

@@ -85,26 +85,31 @@ def test_hamming_planted_matches_recovered(device):
     assert np.array_equal(idx, ri) and np.array_equal(d1.cpu().numpy()[0], r1) and np.array_equal(d2.cpu().numpy()[0], r2)
 
 
+PRECISIONS = [0, 1]     # f32 MFMA kernel / bf16x3 filter + exact re-rank: same bit-exact contract
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("nq,nt,dim", [(1, 1, 128), (5, 3, 128), (64, 64, 128), (300, 1000, 128), (1000, 257, 128),
                                         (2048, 2048, 128), (333, 555, 64)])
-def test_l2_parity_bit_exact(device, nq, nt, dim):
+def test_l2_parity_bit_exact(device, nq, nt, dim, precision):
     rng = np.random.default_rng(nq * 31 + nt + dim)
     q = synthetic.sift_like(rng, nq, dim)
     t = synthetic.sift_like(rng, nt, dim)
-    idx, d1, d2 = matching.match_l2(_t(q[None], device), _t(t[None], device))
+    idx, d1, d2 = matching.match_l2(_t(q[None], device), _t(t[None], device), precision=precision)
     ri, r1, r2 = orc.match_l2_top2(q, t)
     assert np.array_equal(idx.cpu().numpy()[0], ri)
     assert np.array_equal(d1.cpu().numpy()[0].view(np.uint32), r1.view(np.uint32))
     assert np.array_equal(d2.cpu().numpy()[0].view(np.uint32), r2.view(np.uint32))
 
 
-def test_l2_signed_data_and_duplicates(device):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_l2_signed_data_and_duplicates(device, precision):
     """General (signed) data and exact duplicate train rows: ties -> lowest index, d1 == d2."""
     rng = np.random.default_rng(17)
     t = rng.standard_normal((500, 128)).astype(np.float32)
     t[400] = t[7]; t[450] = t[7]
     q = np.concatenate([t[[7, 400]], rng.standard_normal((30, 128)).astype(np.float32)])
-    idx, d1, d2 = matching.match_l2(_t(q[None], device), _t(t[None], device))
+    idx, d1, d2 = matching.match_l2(_t(q[None], device), _t(t[None], device), precision=precision)
     ri, r1, r2 = orc.match_l2_top2(q, t)
     assert np.array_equal(idx.cpu().numpy()[0], ri) and idx.cpu().numpy()[0][0] == 7 and idx.cpu().numpy()[0][1] == 7
     assert np.array_equal(d1.cpu().numpy()[0].view(np.uint32), r1.view(np.uint32))
@@ -130,13 +135,68 @@ def test_l2_match_set_agreement_with_float64(device):
     assert (idx[pl] == sc["partner"][pl]).mean() > 0.99
 
 
-def test_l2_batched_ragged(device):
+def _assert_same_bits(a, b):
+    for x, y in zip(a, b):
+        x, y = x.cpu().numpy(), y.cpu().numpy()
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_l2_filter_adversarial_inputs(device):
+    """The candidate filter against inputs built to break it; the f32 kernel (oracle-checked above) is the
+    reference at these sizes.  (a) train rows sorted by increasing similarity: every row beats the running
+    bound, the lists overflow and the exact fallback scan must take over; (b) all train rows identical: every
+    row ties; (c) wide dynamic range: row norms from 1e-3 to 1e3, the error band is set by the largest norm;
+    (d) near-duplicates differing in the last bits: ordering decided below the bf16x3 resolution."""
+    rng = np.random.default_rng(99)
+    q = synthetic.sift_like(rng, 700, 128)
+    # (a)
+    t = synthetic.sift_like(rng, 3000, 128)
+    order = np.argsort((t @ q[0]) - 0.5 * (t * t).sum(1))
+    ta = t[order]
+    # (b)
+    tb = np.repeat(t[:1], 1500, axis=0)
+    # (c)
+    tc = (t[:2000] * np.exp(rng.uniform(np.log(1e-3), np.log(1e3), (2000, 1)))).astype(np.float32)
+    qc = (q * np.exp(rng.uniform(np.log(1e-3), np.log(1e3), (700, 1)))).astype(np.float32)
+    # (d)
+    base = synthetic.sift_like(rng, 40, 128)
+    td = np.repeat(base, 50, axis=0)
+    td = (td.view(np.uint32) + rng.integers(0, 4, td.shape, dtype=np.uint32)).view(np.float32)
+    for qq, tt in ((q, ta), (q, tb), (qc, tc), (np.concatenate([base, q[:100]]), td)):
+        a = matching.match_l2(_t(qq[None], device), _t(tt[None], device), precision=0)
+        f = matching.match_l2(_t(qq[None], device), _t(tt[None], device), precision=1)
+        _assert_same_bits(a, f)
+    ri, r1, r2 = orc.match_l2_top2(q, ta)
+    f = matching.match_l2(_t(q[None], device), _t(ta[None], device), precision=1)
+    assert np.array_equal(f[0].cpu().numpy()[0], ri)
+
+
+def test_l2_filter_full_size_equals_f32_kernel(device):
+    """BASELINE cfg 2 shape, 16 pairs of 8192 x 8192 x 128 (no train split): both algorithms, same bits."""
+    rng = np.random.default_rng(5)
+    V = 6
+    tab = np.stack([synthetic.sift_like(rng, 8192, 128) for _ in range(V)])
+    tab[1, :4000] = synthetic.perturb_sift(rng, tab[0, :4000], 0.05)
+    vq = np.arange(16, dtype=np.int32) % V; vt = (np.arange(16, dtype=np.int32) * 5 + 1) % V
+    d = _t(tab, device)
+    a = matching.match_l2(d, d, _t(vq, device), _t(vt, device), precision=0)
+    f = matching.match_l2(d, d, _t(vq, device), _t(vt, device), precision=1)
+    _assert_same_bits(a, f)
+    one = matching.match_l2(d[:1], d[1:2], precision=1)           # single pair: train rows split over blocks
+    a1 = matching.match_l2(d[:1], d[1:2], precision=0)
+    _assert_same_bits(a1, one)
+    assert (one[0][0, :4000].cpu().numpy() == np.arange(4000)).mean() > 0.99
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_l2_batched_ragged(device, precision):
     rng = np.random.default_rng(2)
     tab = np.stack([synthetic.sift_like(rng, 400, 128) for _ in range(4)])
     vq = np.array([0, 1, 2], np.int32); vt = np.array([3, 0, 1], np.int32)
     n_q = np.array([400, 77, 0], np.int32); n_t = np.array([1, 400, 400], np.int32)
     d = _t(tab, device)
-    idx, d1, d2 = matching.match_l2(d, d, _t(vq, device), _t(vt, device), _t(n_q, device), _t(n_t, device))
+    idx, d1, d2 = matching.match_l2(d, d, _t(vq, device), _t(vt, device), _t(n_q, device), _t(n_t, device),
+                                    precision=precision)
     idx, d1, d2 = idx.cpu().numpy(), d1.cpu().numpy(), d2.cpu().numpy()
     for b in range(3):
         ri, r1, r2 = orc.match_l2_top2(tab[vq[b], :n_q[b]], tab[vt[b], :n_t[b]])
