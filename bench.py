@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=16, help="pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed through the CPU oracle (0 = skip)")
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
@@ -182,7 +182,10 @@ def main():
         # per algorithmic product (+3 % priming), so its ceiling on this scale is a third of the bf16 peak.
         roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
                     "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "launch_ms": kern_ms,
+                    "frac": achieved / PEAK_BF16_MFMA_TFLOPS,
+                    # HBM bytes per launch of 16 pairs, rocprofv3 --pmc offline (profiles/r1/l2_filter_pmc_summary.json):
+                    # FETCH_SIZE x2 (gfx950 correction) 135 MB filter + 185 MB re-rank, WRITE_SIZE 33 MB; scaled by pairs
+                    "traffic": 353.0e6 * P / 16, "launch_ms": kern_ms,
                     "algorithmic_flops_per_launch": flops, "executed_bf16_mfma_flops_per_launch": flops * 3 * (1 + 8 / 256),
                     "executed_frac_of_bf16_peak": achieved * 3 * (1 + 8 / 256) / PEAK_BF16_MFMA_TFLOPS,
                     "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,

@@ -186,16 +186,23 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
         acc1 = acc0;
         const uint4* rh = &tile_hi[buf][li * kCPR];
         const uint4* rl = &tile_lo[buf][li * kCPR];
+        // A fragments one k-step ahead in registers: the LDS latency of step s+1 hides under the six MFMAs of step s
+        uint4 ah = rh[h ^ (li & 15)], al = rl[h ^ (li & 15)];
 #pragma unroll
         for (int s = 0; s < kNS; ++s) {
-            const uint4 ah = rh[(2 * s + h) ^ (li & 15)];
-            const uint4 al = rl[(2 * s + h) ^ (li & 15)];
+            uint4 nh = ah, nl = al;
+            if (s + 1 < kNS) {
+                nh = rh[(2 * s + 2 + h) ^ (li & 15)];
+                nl = rl[(2 * s + 2 + h) ^ (li & 15)];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the two reads above the MFMAs (the scheduler would sink them)
             acc0 = mfma_bf16(ah, bh[0][s], acc0);
             acc1 = mfma_bf16(ah, bh[1][s], acc1);
             acc0 = mfma_bf16(al, bh[0][s], acc0);
             acc1 = mfma_bf16(al, bh[1][s], acc1);
             acc0 = mfma_bf16(ah, bl[0][s], acc0);
             acc1 = mfma_bf16(ah, bl[1][s], acc1);
+            ah = nh; al = nl;
         }
     };
 
