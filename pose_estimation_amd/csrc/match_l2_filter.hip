@@ -13,9 +13,10 @@
 // lane), both of the exact top-2 rows have sA >= a2 - 2 e_i: such rows are appended to a candidate list.  Every
 // (query, train split, lane half) owns a private list segment and counts in a register, so an append is one
 // fire-and-forget store: no atomics, nothing to wait for.  A short priming pass over the first tiles sets the bound before anything
-// is appended, so a query collects ~10 candidates out of 8192 rows.
+// is appended, so a query collects ~10 candidates out of 8192 rows.  A list entry is (row, sA).
 //
-// Re-rank.  l2_rerank_kernel evaluates the contract's exact chain (k order 8c+{0,4,1,5,2,6,3,7}, start
+// Re-rank.  l2_rerank_kernel first prunes the list with the FINAL bound (second-largest listed sA - 2 e_i: 2-3 rows
+// survive), then evaluates the contract's exact chain (k order 8c+{0,4,1,5,2,6,3,7}, start
 // -|t|^2/2) for the listed rows, takes (max s, lowest index on ties) and the runner-up, and writes idx/d1sq/d2sq
 // exactly as the f32 kernel does.  A list that overflowed its capacity (adversarially ordered input) makes the
 // query fall back to the exact chain over ALL rows inside the same kernel: slower, never wrong.
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int rows_per_split,
     const float* __restrict__ tnorm, const float* __restrict__ qnorm, const float* __restrict__ tmax,
-    int32_t* __restrict__ cnt, int32_t* __restrict__ list, int slots, int nqb, int B) {
+    int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
     constexpr int STG = kTR * kCPR / NT;          // 8-float groups staged per thread per tile
     __shared__ uint4 tile_hi[2][kTR * kCPR];
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
     // and every test uses the current value.
     auto hit = [&](float v, int j, int ct) {
         if (v >= thr[ct]) {
-            if (nc[ct] < kCapH) list[qoff[ct] * kCapH + nc[ct]] = j;
+            if (nc[ct] < kCapH) list[qoff[ct] * kCapH + nc[ct]] = make_int2(j, __float_as_int(v));
             ++nc[ct];
             a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], v);
             a1[ct] = vmax(a1[ct], v);
@@ -311,19 +312,30 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
     return acc;
 }
 
-// Re-rank: 16 lanes per query (four queries per wave), one candidate row per lane and round.  A lane walking its
-// own 512-byte row would make every load instruction touch 64 different cache lines, so the rows are fetched
-// cooperatively instead — 16 consecutive lanes read one 256-byte half row — and transposed through LDS
-// (swizzled 16-byte chunks); each lane then reads its own row from LDS and runs the exact fma chain.
+// Re-rank: 16 lanes per query, four queries per wave.  The kernel is a chain of dependent memory round trips, so it is
+// organised to make them few and wide: (1) the wave's four query rows go to LDS once; (2) every lane reads its list
+// entries of all segments at once and the query's final bound (second-largest listed sA - 2e) is formed by shuffles;
+// (3) the surviving entries of all four queries (2-3 each) are compacted into a wave queue in LDS; (4) the queued rows
+// are fetched whole, 16 at a time, by all 64 lanes (coalesced 512-byte rows, swizzled into LDS) and lane r runs the
+// exact fma chain of row r out of LDS; (5) lane 0 of each query folds the results into (best, runner-up).
 constexpr int kRL = 16;
+constexpr int kRQ = 64 / kRL;          // queries per wave
+constexpr int kRC = 16;                // rows per fetch chunk
+struct RerankLds {
+    float4 rows[kRC * 32];             // 16 rows x 32 chunks, chunk c of row r at r*32 + (c ^ r)
+    float4 qrow[kRQ * 32];
+    int qj[64 + kRC];
+    int qq[64 + kRC];
+    float rs[kRC];
+};
 __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t, int B, int nq, int nt,
     const float* __restrict__ tnorm, const float* __restrict__ qnorm,
-    const int32_t* __restrict__ cnt, const int32_t* __restrict__ list, int slots,
+    const float* __restrict__ tmax, const int32_t* __restrict__ cnt, const int2* __restrict__ list, int slots,
     int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq) {
-    __shared__ float4 rows[4][64 * 8];                     // per wave: 64 rows x 8 chunks (a 128-byte quarter row each)
+    __shared__ RerankLds lds[4];
     // blocks of one pair share one residue of the block id mod 8 (one XCD, one L2 for the pair's train rows)
     constexpr int QPB = 256 / kRL;
     const int bpp = (nq + QPB - 1) / QPB;                 // blocks per pair
@@ -335,8 +347,8 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         b = blockIdx.x / bpp; bq = blockIdx.x % bpp;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qid = lane / kRL, sl = lane % kRL;          // query within the wave, lane within the query
     const int qi = bq * QPB + threadIdx.x / kRL;
-    const int sl = threadIdx.x % kRL;
     const int vq = view_q ? view_q[b] : b;
     const int vt = view_t ? view_t[b] : b;
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
@@ -346,83 +358,130 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float4* q = (const float4*)(dq + ((size_t)vq * nq + min(qi, nq - 1)) * kDim);
     const float4* Tt = (const float4*)(dt + (size_t)vt * nt * kDim);
     const float* TN = tnorm + (size_t)vt * nt;
-    float4* my = rows[wave];
-
-    float m1 = -INFINITY, m2 = -INFINITY;
-    int32_t bi = PH_NO_INDEX;
-    auto keep = [&](float s, int j) {
-        const bool better = (s > m1) || (s == m1 && (bi < 0 || j < bi));
-        m2 = better ? m1 : fmaxf(m2, s);
-        bi = better ? j : bi;
-        m1 = better ? s : m1;
+    RerankLds& L = lds[wave];
+    auto wave_sync = [] {                                  // the LDS block belongs to this wave alone; its LDS operations
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // complete in order: only the compiler needs the fence
+        __builtin_amdgcn_wave_barrier();
     };
 
-    // this lane's entries: the query's list segments laid end to end, entry g = sl, sl + 16, ...
-    int total = 0;
+    // (1) query rows -> LDS: lane (qid, sl) copies chunks sl and sl + 16 of its query
+    L.qrow[qid * 32 + sl] = q[sl];
+    L.qrow[qid * 32 + sl + 16] = q[sl + 16];
+
+    // (2) list entries of this lane (entries sl and sl + 16 of every segment) and the final bound
     bool overflow = false;
+    float p1 = -INFINITY, p2 = -INFINITY;
     if (live)
         for (int slot = 0; slot < slots; ++slot) {
             const int c = cnt[o * slots + slot];
+            const int2 e0 = list[(o * slots + slot) * kCapH + sl], e1 = list[(o * slots + slot) * kCapH + sl + 16];
             overflow |= c > kCapH;
-            total += min(c, kCapH);
+            if (sl < c) { const float v = __int_as_float(e0.y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
+            if (sl + 16 < c) { const float v = __int_as_float(e1.y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
         }
-    if (overflow) total = 0;
-    int rounds = (total + kRL - 1) / kRL;
-    for (int w = 32; w > 0; w >>= 1) rounds = max(rounds, __shfl_xor(rounds, w));     // wave-uniform trip count
-    for (int rd = 0; rd < rounds; ++rd) {
-        const int g = rd * kRL + sl;
-        int j = -1;
-        if (g < total) {
-            int base = 0;
-            for (int slot = 0; slot < slots; ++slot) {
-                const int cc = min(cnt[o * slots + slot], kCapH);
-                if (g < base + cc) { j = list[(o * slots + slot) * kCapH + (g - base)]; break; }
-                base += cc;
-            }
-        }
-        float acc = (j >= 0) ? -0.5f * TN[j] : 0.0f;
 #pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            // cooperative fetch: in step i lanes 8g..8g+7 read the quarter row of the candidate held by lane 8i+g.
-            // The LDS region belongs to this wave alone and a wave's LDS operations complete in order, so only the
-            // compiler has to be kept from reordering across the transposition.
+    for (int w = kRL / 2; w > 0; w >>= 1) {
+        const float o1 = __shfl_xor(p1, w), o2 = __shfl_xor(p2, w);
+        p2 = fmaxf(fminf(p1, o1), fmaxf(p2, o2));
+        p1 = fmaxf(p1, o1);
+        overflow |= (bool)__shfl_xor((int)overflow, w);
+    }
+    // The two rows with the largest approximate scores are in the list (they passed every running bound), so the
+    // second-largest LISTED sA is the query's true second-largest, and only rows with sA >= that - 2e can be one of
+    // the exact top-2: typically 2-3 of the ~11 listed rows.
+    const float Tm = tmax[b];
+    const float bound = p2 - 2.0f * kEpsScale * (sqrtf(qnorm[(size_t)vq * nq + min(qi, nq - 1)]) * Tm + 0.5f * Tm * Tm);
+
+    float m1 = -INFINITY, m2 = -INFINITY;
+    int32_t bi = PH_NO_INDEX;
+    auto keep = [&](float sc, int j) {
+        const bool better = (sc > m1) || (sc == m1 && (bi < 0 || j < bi));
+        m2 = better ? m1 : fmaxf(m2, sc);
+        bi = better ? j : bi;
+        m1 = better ? sc : m1;
+    };
+
+    // (4) + (5) for the first n queued rows
+    auto flush = [&](int n) {
+        for (int base = 0; base < n; base += kRC) {
+            const int k = min(kRC, n - base);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int r = 8 * i + (lane >> 3);
-                const int jr = __shfl(j, r);
-                const int c = lane & 7;
-                if (jr >= 0) my[r * 8 + (c ^ (r & 7))] = Tt[(size_t)jr * (kDim / 4) + qt * 8 + c];
+                const int id = lane + 64 * i, r = id >> 5, c = id & 31;
+                if (r < k) L.rows[r * 32 + (c ^ r)] = Tt[(size_t)L.qj[base + r] * (kDim / 4) + c];
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (j >= 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 q0 = q[qt * 8 + 2 * c], q1 = q[qt * 8 + 2 * c + 1];
-                    const float4 t0 = my[lane * 8 + ((2 * c) ^ (lane & 7))], t1 = my[lane * 8 + ((2 * c + 1) ^ (lane & 7))];
+            wave_sync();
+            if (lane < k) {
+                const int r = lane, jr = L.qj[base + r];
+                const float4* qr = &L.qrow[L.qq[base + r] * 32];
+                float acc = -0.5f * TN[jr];
+#pragma unroll 4
+                for (int c = 0; c < 16; ++c) {
+                    const float4 q0 = qr[2 * c], q1 = qr[2 * c + 1];
+                    const float4 t0 = L.rows[r * 32 + ((2 * c) ^ r)], t1 = L.rows[r * 32 + ((2 * c + 1) ^ r)];
                     acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
                     acc = ph_fma(t0.y, q0.y, acc); acc = ph_fma(t1.y, q1.y, acc);
                     acc = ph_fma(t0.z, q0.z, acc); acc = ph_fma(t1.z, q1.z, acc);
                     acc = ph_fma(t0.w, q0.w, acc); acc = ph_fma(t1.w, q1.w, acc);
                 }
+                L.rs[r] = acc;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_sync();
+            if (sl == 0)
+                for (int r = 0; r < k; ++r)
+                    if (L.qq[base + r] == qid) keep(L.rs[r], L.qj[base + r]);
+            wave_sync();
         }
-        if (j >= 0) keep(acc, j);
+    };
+
+    // (3) compaction of the surviving entries of the four queries into the wave queue
+    int n = 0;                                             // wave-uniform queue length
+    int max_slots = (live && !overflow) ? slots : 0;
+    for (int w = 32; w > 0; w >>= 1) max_slots = max(max_slots, __shfl_xor(max_slots, w));
+    wave_sync();
+    for (int slot = 0; slot < max_slots; ++slot) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            int j = -1;
+            if (live && !overflow) {
+                const int c = min(cnt[o * slots + slot], kCapH);
+                const int2 e = list[(o * slots + slot) * kCapH + sl + 16 * pass];
+                if (sl + 16 * pass < c && __int_as_float(e.y) >= bound) j = e.x;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(j >= 0);
+            if (m == 0ull) continue;
+            if (j >= 0) {
+                const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                L.qj[pos] = j; L.qq[pos] = qid;
+            }
+            n += __builtin_popcountll(m);
+            if (n >= kRC) {                                // keep the queue within its 64 + 16 entries
+                wave_sync();
+                const int full = n & ~(kRC - 1);
+                flush(full);
+                if (lane < n - full) { const int a = L.qj[full + lane], c2 = L.qq[full + lane]; wave_sync(); L.qj[lane] = a; L.qq[lane] = c2; }
+                n -= full;
+                wave_sync();
+            }
+        }
     }
+    wave_sync();
+    flush(n);
+
+    if (overflow && sl == 0) { m1 = -INFINITY; m2 = -INFINITY; bi = PH_NO_INDEX; }
     if (overflow)                                          // a segment overflowed: exact scan of every row instead
         for (int j = sl; j < ntv; j += kRL) keep(exact_score(q, Tt + (size_t)j * (kDim / 4), TN[j]), j);
-    // butterfly over the lanes of the query
+    if (overflow) {                                        // butterfly over the lanes of the query
 #pragma unroll
-    for (int w = kRL / 2; w > 0; w >>= 1) {
-        const float om1 = __shfl_xor(m1, w), om2 = __shfl_xor(m2, w);
-        const int32_t obi = __shfl_xor(bi, w);
-        const bool other = (obi >= 0) && ((om1 > m1) || (om1 == m1 && (bi < 0 || obi < bi)));
-        const float lost = other ? m1 : om1;
-        m2 = fmaxf(lost, fmaxf(m2, om2));
-        m1 = other ? om1 : m1;
-        bi = other ? obi : bi;
+        for (int w = kRL / 2; w > 0; w >>= 1) {
+            const float om1 = __shfl_xor(m1, w), om2 = __shfl_xor(m2, w);
+            const int32_t obi = __shfl_xor(bi, w);
+            const bool other = (obi >= 0) && ((om1 > m1) || (om1 == m1 && (bi < 0 || obi < bi)));
+            const float lost = other ? m1 : om1;
+            m2 = fmaxf(lost, fmaxf(m2, om2));
+            m1 = other ? om1 : m1;
+            bi = other ? obi : bi;
+        }
     }
     if (sl == 0 && qi < nq) {
         if (!live) { idx[o] = PH_NO_INDEX; d1sq[o] = INFINITY; d2sq[o] = INFINITY; return; }
@@ -452,7 +511,7 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
     p.slots = 2 * p.splits;
     p.off_cnt = ((size_t)B * sizeof(float) + 255) / 256 * 256;
     p.off_list = p.off_cnt + ((size_t)B * nq * p.slots * sizeof(int32_t) + 255) / 256 * 256;
-    p.total = p.off_list + (size_t)B * nq * p.slots * kCapH * sizeof(int32_t);
+    p.total = p.off_list + (size_t)B * nq * p.slots * kCapH * sizeof(int2);
     return p;
 }
 
@@ -462,7 +521,7 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
     const L2FilterPlan p = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
     float* tmax = (float*)ws;
     int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
-    int32_t* list = (int32_t*)((char*)ws + p.off_list);
+    int2* list = (int2*)((char*)ws + p.off_list);
     hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, view_t, n_t, nq, nt, p.slots, tmax, cnt);
     if (nt > 0) {
         const int nqb = ph_ceil_div(nq, kWaves * 64);
@@ -472,6 +531,6 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
     }
     const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
     hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
-                       view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, cnt, list, p.slots, idx, d1sq, d2sq);
+                       view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tmax, cnt, list, p.slots, idx, d1sq, d2sq);
     return ph_launch_status();
 }
