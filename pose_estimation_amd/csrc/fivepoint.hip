@@ -56,18 +56,21 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const int32_
 }
 
 // Stage 1: one thread per minimal sample builds the degree-10 polynomial (sections 1-8 of the core).
-// Blocks are 32 threads wide on purpose: the work is a long dependent chain per sample over ~3.3 KB of
-// dynamically indexed working arrays, kept in LDS (32 x 3336 B per block), and with only B*S samples
-// the launch is latency-bound — more, narrower blocks spread the samples over all CUs.
+// Blocks are narrow on purpose: the work is a long dependent chain per sample over ~3 KB of dynamically
+// indexed working arrays, kept in LDS (one Work5 per thread), and with only B*S samples the launch is
+// latency-bound — narrow blocks spread the samples over all CUs.  32 threads per block while that gives at most
+// one block per CU; beyond, up to 52 (52 x 2984 B = 155 KB, the most one CU's LDS holds), so that e.g.
+// 32 pairs x 410 samples still run as ONE round of 256 blocks instead of two.
 constexpr int kPolyThreads = 32;
-__global__ __launch_bounds__(kPolyThreads) void fivepoint_poly_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+constexpr int kPolyThreadsMax = 52;
+__global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
                                                                      const float* __restrict__ x2, const float* __restrict__ y2,
                                                                      const int32_t* __restrict__ samples, int S, int N,
                                                                      ph5::Poly5* __restrict__ polys) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ph5::Work5* work = reinterpret_cast<ph5::Work5*>(smem);
     const int b = blockIdx.y;
-    const int s = blockIdx.x * kPolyThreads + threadIdx.x;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     ph5::Poly5* out = polys + (size_t)b * S + s;
     const int32_t* si = samples + ((size_t)b * S + s) * 5;
@@ -170,12 +173,14 @@ extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const fl
     if (!ws || ws_bytes < ph_solve_essential_5pt_ws_bytes(B, S) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     ph5::Poly5* polys = (ph5::Poly5*)ws;
-    const size_t lds = sizeof(ph5::Work5) * kPolyThreads;      // 106,752 B: above the 64 KiB default, opt in
-    if (hipFuncSetAttribute((const void*)fivepoint_poly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
+    int threads = kPolyThreads;
+    while (threads < kPolyThreadsMax && (long)B * ph_ceil_div(S, threads) > 256) threads += 4;
+    const size_t lds = sizeof(ph5::Work5) * threads;           // up to 155 KB: above the 64 KiB default, opt in
+    if (hipFuncSetAttribute((const void*)fivepoint_poly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(ph5::Work5) * kPolyThreadsMax)) != hipSuccess)
         return PH_ERR_LAUNCH;
-    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3(ph_ceil_div(S, kPolyThreads), B), dim3(kPolyThreads), lds, st, x1, y1, x2,
-                       y2, samples, S, N, polys);
+    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3(ph_ceil_div(S, threads), B), dim3(threads), lds, st, x1, y1, x2, y2,
+                       samples, S, N, polys);
     const long n_samples = (long)B * S;
     hipLaunchKernelGGL(fivepoint_roots_kernel, dim3((unsigned)((n_samples + 5) / 6)), dim3(64), 0, st, polys, n_samples, E,
                        n_solutions);

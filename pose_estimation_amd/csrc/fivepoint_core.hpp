@@ -55,19 +55,22 @@ struct Poly5 {
 
 // Working arrays of the polynomial stage.  They are indexed dynamically (pivoting), so on the device they
 // would live in private memory (HBM-backed); the kernel puts one Work5 per thread in LDS instead.
-// sizeof(Work5) = 8 * 417 bytes: an odd number of 8-byte words, so that the lanes of a wave touching the
-// same field hit distinct LDS banks.
+// sizeof(Work5) = 8 * 373 bytes: an odd number of 8-byte words, so that the lanes of a wave touching the
+// same field hit distinct LDS banks.  Q (the 5x9 epipolar system) is dead once the null-space basis is out and
+// shares its storage with EEt, which is first written after that.
 struct Work5 {
-    double Q[5][9];
+    union {
+        double Q[5][9];
+        double EEt[3][3][10];
+    };
     double Ep[9][4];
-    double EEt[3][3][10];
     double tr[10];
     double A[10][20];
     double tmp[20], d2[10];
     int perm[10];
-    double pad;
+    double pad[2];
 };
-static_assert(sizeof(Work5) == 8 * 417, "Work5 must be an odd number of 8-byte words");
+static_assert(sizeof(Work5) == 8 * 373, "Work5 must be an odd number of 8-byte words");
 
 // Sections 1-8: minimal sample -> polynomial.  pts[r] = (x1, y1, x2, y2).
 PH_HD inline bool build_polynomial(const double (&pts)[5][4], Poly5& P, Work5& w) {
