@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64) void fivepoint_roots_kernel(const ph5::Poly5* _
             z.re -= w.re; z.im -= w.im;
             change = (fabs(w.re) + fabs(w.im)) / (fabs(z.re) + fabs(z.im) + 1e-30);
         }
-        if (__all(change < ph5::kAberthTol)) break;                // wave-uniform exit
+        if (__all(change < ph5::aberth_tol(it))) break;            // wave-uniform exit
     }
     float e9[9];
     bool real = false;
