@@ -113,6 +113,175 @@ __global__ __launch_bounds__(256) void hamming_top2_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Matrix-core path.  For 0/1 vectors  d(q, t) = |q| + |t| - 2 q.t, so the Hamming matcher is an integer GEMM:
+// descriptor bits are expanded to bytes (train rows 0/1 into LDS, query rows 0/2 into registers) and
+// v_mfma_i32_32x32x32_i8 accumulates  S = 2 q.t - |t|  on top of a C operand preset to -|t| per train row.  For one
+// query, min d <=> max S, exactly (integers).  The accumulator has the query on the lane and 16 train rows in the
+// lane's registers (same orientation as the L2 matcher), so top-2 is an in-lane scan in increasing row order; a tile
+// is scanned only if some lane's tile maximum beats its current runner-up, which after the first few tiles is rare.
+// Work per descriptor pair: 256 int8 MACs on the matrix core instead of 8 xor + 8 popcount + 3 top-2 VALU ops.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMR = 32;                           // train rows per MFMA tile
+constexpr int kNoScore = -(1 << 30);
+
+// 16 descriptor bits -> 16 bytes (one per bit), bit i in byte i; `one` = 0x01010101 (train) or 0x02020202 (query)
+__device__ __forceinline__ uint4 expand16(uint32_t hw, uint32_t one) {
+    uint32_t d[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t spread = (((hw >> (4 * g)) & 0xFu) * 0x00204081u) & 0x01010101u;   // bits 0..3 -> bytes 0..3
+        d[g] = spread * (one & 0xFFu);
+    }
+    return make_uint4(d[0], d[1], d[2], d[3]);
+}
+// plain C++ on purpose: the operands are fresh MFMA results, and the compiler only pads the MFMA -> VALU read
+// hazard for instructions it can see into (inline asm reading the accumulator right after the last MFMA read stale
+// registers).  Both forms are matched to v_med3_i32 / v_max3_i32.
+__device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
+__device__ __forceinline__ int max3_i32(int a, int b, int c) { return max(max(a, b), c); }
+
+template <int QT>
+__global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
+    const uint4* __restrict__ dq, const uint32_t* __restrict__ dt,
+    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
+    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
+    int nq, int nt, int splits, int rows_per_split,
+    int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
+    uint2* __restrict__ partial) {
+    __shared__ uint4 tile[2][kMR * 16];           // 32 rows x 256 expanded bytes, 16-byte chunk c of row r at c ^ (r & 15)
+    __shared__ int4 tneg[2][kMR / 4];             // -|t| per row (the C operand); padded rows: kNoScore
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, split = blockIdx.y;
+    const int vq = view_q ? view_q[b] : b;
+    const int vt = view_t ? view_t[b] : b;
+    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const uint4* Q = dq + (size_t)vq * nq * 2;
+    const uint32_t* T = dt + (size_t)vt * nt * 8;
+    const int qw0 = (blockIdx.x * 4 + wave) * (32 * QT);
+
+    // B fragments: k-step s of lane half h covers descriptor bits 32s + 16h .. +15
+    uint4 bq[QT][8];
+    int pq[QT], m1[QT], m2[QT], bi[QT];
+#pragma unroll
+    for (int ct = 0; ct < QT; ++ct) {
+        const int qi = qw0 + ct * 32 + li;
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (qi < nqv) { a = Q[(size_t)qi * 2]; c = Q[(size_t)qi * 2 + 1]; }
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        pq[ct] = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            bq[ct][s] = expand16((w[s] >> (16 * h)) & 0xFFFFu, 0x02020202u);
+            pq[ct] += __popc(w[s]);
+        }
+        m1[ct] = kNoScore; m2[ct] = kNoScore; bi[ct] = PH_NO_INDEX;
+    }
+
+    const int t_begin = split * rows_per_split;
+    const int t_end = min(ntv, t_begin + rows_per_split);
+
+    // thread tid stages dword (tid & 7) of tile row (tid >> 3): 32 bits -> two 16-byte chunks
+    const int srow = tid >> 3, spart = tid & 7;
+    auto fetch = [&](int t0) -> uint32_t { return (t0 + srow < t_end) ? T[(size_t)(t0 + srow) * 8 + spart] : 0u; };
+    auto commit = [&](int buf, uint32_t wd, int t0) {
+        tile[buf][srow * 16 + ((2 * spart) ^ (srow & 15))] = expand16(wd & 0xFFFFu, 0x01010101u);
+        tile[buf][srow * 16 + ((2 * spart + 1) ^ (srow & 15))] = expand16(wd >> 16, 0x01010101u);
+        int pc = __popc(wd);
+        pc += __shfl_xor(pc, 1); pc += __shfl_xor(pc, 2); pc += __shfl_xor(pc, 4);
+        if (spart == 0) ((int*)tneg[buf])[srow] = (t0 + srow < t_end) ? -pc : kNoScore;
+    };
+    auto scan = [&](const i32x16& acc, int ct, int t0) {
+        int mx = max3_i32(acc[0], acc[1], acc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = max3_i32(mx, acc[r], acc[r + 1]);
+        mx = max(mx, acc[15]);
+        if (__builtin_amdgcn_ballot_w64(mx > m2[ct]) == 0ull) return;
+        const int jb = t0 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {           // increasing row index: strict '>' keeps the lowest index
+            const int v = acc[r];
+            const bool gt = v > m1[ct];
+            m2[ct] = med3_i32(m1[ct], m2[ct], v);
+            m1[ct] = gt ? v : m1[ct];
+            bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
+        }
+    };
+
+    if (t_begin < t_end) {
+        uint32_t stage = fetch(t_begin);
+        int cur = 0;
+        for (int t0 = t_begin; t0 < t_end; t0 += kMR) {
+            commit(cur, stage, t0);
+            __syncthreads();                       // tile[cur] visible; tile[cur^1] free again
+            if (t0 + kMR < t_end) stage = fetch(t0 + kMR);
+            i32x16 acc[QT];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int4 z = tneg[cur][2 * g + h];   // rows 8g + 4h .. +3
+                acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
+            }
+#pragma unroll
+            for (int ct = 1; ct < QT; ++ct) acc[ct] = acc[0];
+            const uint4* trow = &tile[cur][li * 16];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const i32x4 a = __builtin_bit_cast(i32x4, trow[(2 * s + h) ^ (li & 15)]);
+#pragma unroll
+                for (int ct = 0; ct < QT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, __builtin_bit_cast(i32x4, bq[ct][s]), acc[ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ct = 0; ct < QT; ++ct) scan(acc[ct], ct, t0);
+            cur ^= 1;
+        }
+    }
+
+    // merge the two lane halves (same query, disjoint train rows), then emit distances d = |q| - S
+#pragma unroll
+    for (int ct = 0; ct < QT; ++ct) {
+        const int om1 = __shfl_xor(m1[ct], 32), om2 = __shfl_xor(m2[ct], 32), obi = __shfl_xor(bi[ct], 32);
+        const bool other = (om1 > m1[ct]) || (om1 == m1[ct] && obi >= 0 && (bi[ct] < 0 || obi < bi[ct]));
+        const int lost = other ? m1[ct] : om1;
+        const int nm2 = max(lost, max(m2[ct], om2));
+        const int nm1 = other ? om1 : m1[ct];
+        const int nbi = other ? obi : bi[ct];
+        const int qi = qw0 + ct * 32 + li;
+        if (h != 0 || qi >= nq) continue;
+        uint32_t k1 = kNoKey, k2 = kNoKey;
+        if (qi < nqv && nbi >= 0) {
+            k1 = ((uint32_t)(pq[ct] - nm1) << kIdxBits) + (uint32_t)nbi;
+            if (nm2 != kNoScore) k2 = ((uint32_t)(pq[ct] - nm2) << kIdxBits) + kIdxMask;   // runner-up: distance only
+        }
+        if (splits == 1) emit(k1, k2, idx, d1, d2, (size_t)b * nq + qi);
+        else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(k1, k2);
+    }
+}
+
+struct HammingMfmaPlan { int qt, splits, rows_per_split; };
+HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
+    HammingMfmaPlan p;
+    const long target = 512;                                   // two 4-wave blocks per CU
+    p.qt = 4;
+    while (p.qt > 1 && (long)B * ph_ceil_div(nq, 128 * p.qt) < target) p.qt >>= 1;
+    const long blocks = (long)B * ph_ceil_div(nq, 128 * p.qt);
+    int s = (int)((target + blocks - 1) / blocks);
+    const int max_s = ph_ceil_div(nt, 8 * kMR);                // at least 8 tiles per split
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kMR) * kMR;
+    if (p.rows_per_split < kMR) p.rows_per_split = kMR;
+    p.splits = ph_ceil_div(nt, p.rows_per_split);
+    if (p.splits < 1) p.splits = 1;
+    return p;
+}
+
 __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2* __restrict__ partial, int B, int nq,
                                                            int splits, int32_t* __restrict__ idx,
                                                            int32_t* __restrict__ d1, int32_t* __restrict__ d2) {
@@ -160,7 +329,7 @@ HammingPlan plan_hamming(int B, int nq, int nt) {
 
 extern "C" size_t ph_match_hamming_ws_bytes(int B, int nq, int nt) {
     if (B <= 0 || nq <= 0 || nt <= 0) return 0;
-    const HammingPlan p = plan_hamming(B, nq, nt);
+    const HammingMfmaPlan p = plan_hamming_mfma(B, nq, nt);
     return p.splits > 1 ? sizeof(uint2) * (size_t)B * p.splits * nq : 0;
 }
 
@@ -177,17 +346,17 @@ extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_
     if (!desc_q || !idx || !d1 || !d2 || (nt > 0 && !desc_t)) return PH_ERR_INVALID_ARG;
     if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    HammingPlan p = (nt > 0) ? plan_hamming(B, nq, nt) : HammingPlan{1, 1, kTT};
+    const HammingMfmaPlan p = (nt > 0) ? plan_hamming_mfma(B, nq, nt) : HammingMfmaPlan{1, 1, kMR};
     if (p.splits > 1) {
         if (!ws || ws_bytes < ph_match_hamming_ws_bytes(B, nq, nt) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
     }
-    const dim3 grid(ph_ceil_div(nq, 256 * p.qpt), p.splits, B);
+    const dim3 grid(ph_ceil_div(nq, 128 * p.qt), p.splits, B);
     const uint4* q4 = (const uint4*)desc_q;
-    const uint4* t4 = (const uint4*)desc_t;
+    const uint32_t* t1 = (const uint32_t*)desc_t;
     uint2* part = (uint2*)ws;
-#define PH_LAUNCH(QPT) hipLaunchKernelGGL(hamming_top2_kernel<QPT>, grid, dim3(256), 0, st, q4, t4, view_q, view_t, \
-                                          n_q, n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
-    if (p.qpt == 4) PH_LAUNCH(4); else if (p.qpt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
+#define PH_LAUNCH(QT) hipLaunchKernelGGL(hamming_mfma_kernel<QT>, grid, dim3(256), 0, st, q4, t1, view_q, view_t, n_q, \
+                                         n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
+    if (p.qt == 4) PH_LAUNCH(4); else if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
 #undef PH_LAUNCH
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;

@@ -59,12 +59,10 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// plain v_max_f32 (fmaxf would add a canonicalising v_max v,v,v per operand)
-__device__ __forceinline__ float vmax(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// max as plain C++, never inline asm: the operands are fresh MFMA results, and the compiler pads the MFMA -> VALU
+// read hazard only for instructions it can see into (an asm v_max reading the accumulator right behind the last MFMA
+// reads stale registers).  This file is built with -fno-honor-nans, so fmaxf is a single v_max_f32.
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(const uint4 a, const uint4 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -101,6 +99,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
     __shared__ uint4 tile_hi[2][kTR * kCPR];
     __shared__ uint4 tile_lo[2][kTR * kCPR];
     __shared__ float4 tnl[2][kTR / 4];
+    __shared__ float4 tnl2[2][kTR / 4];           // same values: the second column tile's C operand is read, not copied
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
             tile_hi[buf][row * kCPR + (p ^ (row & 15))] = hi;
             tile_lo[buf][row * kCPR + (p ^ (row & 15))] = lo;
         }
-        if (tid < kTR) ((float*)tnl[buf])[tid] = stage_tn;
+        if (tid < kTR) { ((float*)tnl[buf])[tid] = stage_tn; ((float*)tnl2[buf])[tid] = stage_tn; }
     };
 
     auto tile_scores = [&](int buf, f32x16& acc0, f32x16& acc1) {
@@ -184,7 +183,11 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
             const float4 z = tnl[buf][2 * g + h];      // rows 8g + 4h .. +3
             acc0[4 * g + 0] = z.x; acc0[4 * g + 1] = z.y; acc0[4 * g + 2] = z.z; acc0[4 * g + 3] = z.w;
         }
-        acc1 = acc0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                  // a second LDS read instead of 16 register copies
+            const float4 z = tnl2[buf][2 * g + h];
+            acc1[4 * g + 0] = z.x; acc1[4 * g + 1] = z.y; acc1[4 * g + 2] = z.z; acc1[4 * g + 3] = z.w;
+        }
         const uint4* rh = &tile_hi[buf][li * kCPR];
         const uint4* rl = &tile_lo[buf][li * kCPR];
         // A fragments one k-step ahead in registers: the LDS latency of step s+1 hides under the six MFMAs of step s
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
             a1[ct] = fmaxf(a1[ct], v);
         }
     };
-    // filtering: rows whose approximate score reaches the bound are appended.  A max tree over the 16 accumulator
-    // registers is walked from the root; a subtree is entered only if some lane of the wave has a hit in it, so a
-    // tile with one hit costs ~9 wave-level tests instead of 16 masked blocks.  thr only rises while rows are appended,
+    // filtering: rows whose approximate score reaches the bound are appended.  The 16 accumulator registers are
+    // reduced in four groups of four (v_max3); a group is entered only if some lane of the wave has a hit in it, so a
+    // tile with one hit costs 1 + 4 wave-level tests and 4 masked blocks instead of 16.  thr only rises while rows are appended,
     // and every test uses the current value.
     auto hit = [&](float v, int j, int ct) {
         if (v >= thr[ct]) {
@@ -231,27 +234,16 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
     };
     auto any_ge = [&](float m, int ct) { return __builtin_amdgcn_ballot_w64(m >= thr[ct]) != 0ull; };
     auto filter = [&](const f32x16& acc, int ct, int t0) {
-        float m8[8], m4[4], m2[2];
+        float m4[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) m8[i] = vmax(acc[2 * i], acc[2 * i + 1]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) m4[i] = vmax(m8[2 * i], m8[2 * i + 1]);
-        m2[0] = vmax(m4[0], m4[1]); m2[1] = vmax(m4[2], m4[3]);
-        if (!any_ge(vmax(m2[0], m2[1]), ct)) return;
+        for (int i = 0; i < 4; ++i) m4[i] = vmax(vmax(acc[4 * i], acc[4 * i + 1]), vmax(acc[4 * i + 2], acc[4 * i + 3]));
+        if (!any_ge(vmax(vmax(m4[0], m4[1]), vmax(m4[2], m4[3])), ct)) return;
         const int jb = t0 + 4 * h;
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            if (!any_ge(m2[g2], ct)) continue;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (!any_ge(m4[g4], ct)) continue;
 #pragma unroll
-            for (int g4 = 2 * g2; g4 < 2 * g2 + 2; ++g4) {
-                if (!any_ge(m4[g4], ct)) continue;
-#pragma unroll
-                for (int g8 = 2 * g4; g8 < 2 * g4 + 2; ++g8) {
-                    if (!any_ge(m8[g8], ct)) continue;
-#pragma unroll
-                    for (int r = 2 * g8; r < 2 * g8 + 2; ++r) hit(acc[r], jb + (r & 3) + 8 * (r >> 2), ct);
-                }
-            }
+            for (int r = 4 * g4; r < 4 * g4 + 4; ++r) hit(acc[r], jb + (r & 3) + 8 * (r >> 2), ct);
         }
         thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
     };
@@ -374,10 +366,13 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     if (live)
         for (int slot = 0; slot < slots; ++slot) {
             const int c = cnt[o * slots + slot];
-            const int2 e0 = list[(o * slots + slot) * kCapH + sl], e1 = list[(o * slots + slot) * kCapH + sl + 16];
+            const int2 e0 = list[(o * slots + slot) * kCapH + sl];        // issued together with the count
             overflow |= c > kCapH;
             if (sl < c) { const float v = __int_as_float(e0.y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
-            if (sl + 16 < c) { const float v = __int_as_float(e1.y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
+            if (sl + 16 < c) {                                            // second cache line of the segment: rarely used
+                const float v = __int_as_float(list[(o * slots + slot) * kCapH + sl + 16].y);
+                p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v);
+            }
         }
 #pragma unroll
     for (int w = kRL / 2; w > 0; w >>= 1) {
@@ -445,8 +440,10 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             int j = -1;
             if (live && !overflow) {
                 const int c = min(cnt[o * slots + slot], kCapH);
-                const int2 e = list[(o * slots + slot) * kCapH + sl + 16 * pass];
-                if (sl + 16 * pass < c && __int_as_float(e.y) >= bound) j = e.x;
+                if (sl + 16 * pass < c) {
+                    const int2 e = list[(o * slots + slot) * kCapH + sl + 16 * pass];
+                    if (__int_as_float(e.y) >= bound) j = e.x;
+                }
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(j >= 0);
             if (m == 0ull) continue;
