@@ -20,6 +20,8 @@ from pose_estimation_amd import matching, ransac, synthetic, triangulation  # no
 
 VALU_PEAK = 256 * 4 * 32 * 2.4e9
 MFMA_F32_PEAK = 157.3e12
+MFMA_BF16_PEAK = 2516.6e12   # ~2.5 PF dense nominal (2.4 GHz); 1.25-1.5 PF sustained on random data (MI355X_MICROARCH.md)
+MFMA_I8_PEAK = 5033.2e12     # i8 MFMA: 2x the bf16 rate per clock
 HBM_PEAK = 8.0e12
 
 
@@ -60,9 +62,14 @@ def main():
             tab /= tab.norm(dim=2, keepdim=True)
             vq = torch.arange(0, V, 2, dtype=torch.int32, device=dev); vt = vq + 1
             nrm = matching.row_sqnorm(tab)
-            med, best = timeit(lambda: matching.match_l2(tab, tab, vq, vt, norm_q=nrm, norm_t=nrm), args.iters)
+            med, best = timeit(lambda: matching.match_l2(tab, tab, vq, vt, norm_q=nrm, norm_t=nrm, precision=0), args.iters)
             report("l2_top2_f32_kernel<128>", f"{P} pair(s) 8192x8192x128 f32", med, best, 2.0 * n * n * d * P, "FLOP/s",
                    MFMA_F32_PEAK, {"bound": "mfma", "hbm_frac": (2 * n * d * 4 + n * 12) * P / med / HBM_PEAK})
+            med, best = timeit(lambda: matching.match_l2(tab, tab, vq, vt, norm_q=nrm, norm_t=nrm, precision=1), args.iters)
+            report("l2 filter + re-rank (prep + l2_filter_kernel<4> + l2_rerank_kernel)", f"{P} pair(s) 8192x8192x128 f32",
+                   med, best, 2.0 * n * n * d * P, "FLOP/s", MFMA_BF16_PEAK,
+                   {"bound": "mfma", "note": "algorithmic FLOP over the nominal bf16 peak; 3.09 bf16 MFMA FLOP are executed per "
+                    "algorithmic FLOP", "over_f32_mfma_peak": 2.0 * n * n * d * P / med / MFMA_F32_PEAK})
 
     if not only or "hamming" in only:
         for V, n in ((8, 32768), (32, 8192)):
@@ -71,12 +78,14 @@ def main():
             vq, vt = t(i), t(j)
             B = len(i)
             med, best = timeit(lambda: matching.match_hamming(tab, tab, vq, vt), args.iters)
-            report("hamming_top2_kernel", f"{B} pairs {n}x{n}x256 bit", med, best, 16.0 * n * n * B, "lane-ops/s", VALU_PEAK,
-                   {"bound": "valu", "hbm_frac": (2 * n * 32 + n * 12) * B / med / HBM_PEAK, "pairs_per_s": B / med})
+            # the kernel runs 256 int8 MACs per descriptor pair on the matrix cores (i8 MFMA = 2x the bf16 rate)
+            report("hamming_mfma_kernel<2>", f"{B} pairs {n}x{n}x256 bit", med, best, 512.0 * n * n * B, "OP/s", MFMA_I8_PEAK,
+                   {"bound": "mfma", "hbm_frac": (2 * n * 32 + n * 12) * B / med / HBM_PEAK, "pairs_per_s": B / med,
+                    "valu_equivalent_frac": 16.0 * n * n * B / med / VALU_PEAK})
         tab = torch.randint(0, 256, (2, 32768, 32), dtype=torch.uint8, device=dev)
         med, best = timeit(lambda: matching.match_hamming(tab[0:1], tab[1:2]), args.iters)
-        report("hamming_top2_kernel+merge", "1 pair 32768x32768x256 bit (train split + merge)", med, best,
-               16.0 * 32768 * 32768, "lane-ops/s", VALU_PEAK, {"bound": "valu"})
+        report("hamming_mfma_kernel+merge", "1 pair 32768x32768x256 bit (train split + merge)", med, best,
+               512.0 * 32768 * 32768, "OP/s", MFMA_I8_PEAK, {"bound": "mfma"})
 
     if not only or "score_e" in only:
         for B, H, N in ((16, 4096, 8192), (1, 4096, 8192)):

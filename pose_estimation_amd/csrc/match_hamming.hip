@@ -267,7 +267,7 @@ struct HammingMfmaPlan { int qt, splits, rows_per_split; };
 HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
     HammingMfmaPlan p;
     const long target = 512;                                   // two 4-wave blocks per CU
-    p.qt = 4;
+    p.qt = 2;                                                  // 4 measured the same and spills 30 VGPRs
     while (p.qt > 1 && (long)B * ph_ceil_div(nq, 128 * p.qt) < target) p.qt >>= 1;
     const long blocks = (long)B * ph_ceil_div(nq, 128 * p.qt);
     int s = (int)((target + blocks - 1) / blocks);
@@ -356,7 +356,7 @@ extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_
     uint2* part = (uint2*)ws;
 #define PH_LAUNCH(QT) hipLaunchKernelGGL(hamming_mfma_kernel<QT>, grid, dim3(256), 0, st, q4, t1, view_q, view_t, n_q, \
                                          n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
-    if (p.qt == 4) PH_LAUNCH(4); else if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
+    if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
 #undef PH_LAUNCH
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;
