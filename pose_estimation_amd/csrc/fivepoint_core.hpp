@@ -214,11 +214,11 @@ PH_HD_CONST int kAberthMaxIter = 60;
 PH_HD_CONST double kAberthTol = 1e-13;
 // Ill-conditioned roots jitter at 1e-13..1e-11 relative for ever (rounding noise of the degree-10 Horner sums): about
 // 2 % of the samples never meet 1e-13, and one such sample keeps its whole wave iterating.  The tolerance therefore
-// relaxes by a decade every four iterations after the 14th (the typical sample is done by then): 1e-12 at 18, 1e-11 at
-// 22, ... — every accepted root is still far inside the basin of the Newton polish that follows.
+// relaxes by a decade every three iterations from the 13th on (the typical sample is done by then): 1e-12 at 13, 1e-11
+// at 16, 1e-9 at 22 — every accepted root is still far inside the basin of the Newton polish that follows.
 PH_HD inline double aberth_tol(int it) {
     double t = kAberthTol;
-    for (int k = 18; k <= it; k += 4) t *= 10.0;
+    for (int k = 13; k <= it; k += 3) t *= 10.0;
     return t;
 }
 
