@@ -47,6 +47,39 @@ __global__ __launch_bounds__(256) void l2_sqnorm_kernel(const float* __restrict_
     out[r] = acc;
 }
 
+// The same chain with coalesced loads (dim % 32 == 0): a lane walking its own 512-byte row makes every load touch
+// 64 different cache lines, so each wave fetches 64 rows cooperatively, 128 bytes of a row per 8 lanes, transposes
+// them through a swizzled LDS block of its own, and every lane then sums its own row in natural k order.
+__global__ __launch_bounds__(256) void l2_sqnorm_coalesced_kernel(const float* __restrict__ table, int64_t n_rows, int dim,
+                                                                 float* __restrict__ out) {
+    __shared__ float4 blk[4][64 * 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    if (r0 >= n_rows) return;
+    float4* my = blk[wave];
+    const float4* T = (const float4*)table;
+    const int cpr = dim / 4;
+    float acc = 0.0f;
+    for (int c0 = 0; c0 < cpr; c0 += 8) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * i + (lane >> 3), c = lane & 7;
+            if (r0 + r < n_rows) my[r * 8 + (c ^ (r & 7))] = T[(size_t)(r0 + r) * cpr + c0 + c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the LDS block is this wave's own; a wave's LDS
+        __builtin_amdgcn_wave_barrier();                         // operations complete in order
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 x = my[lane * 8 + (c ^ (lane & 7))];
+            acc = ph_fma(x.x, x.x, acc); acc = ph_fma(x.y, x.y, acc);
+            acc = ph_fma(x.z, x.z, acc); acc = ph_fma(x.w, x.w, acc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (r0 + lane < n_rows) out[r0 + lane] = acc;
+}
+
 __device__ __forceinline__ void write_final(float m1, float m2, int32_t bi, float qn, int32_t* idx, float* d1sq,
                                             float* d2sq, size_t o) {
     idx[o] = bi;
@@ -263,8 +296,12 @@ extern "C" int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float*
     if (n_rows < 0 || dim <= 0 || dim % 4) return PH_ERR_INVALID_ARG;
     if (n_rows == 0) return PH_OK;
     if (!table || !out || !ph_aligned(table, 16)) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(l2_sqnorm_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table,
-                       n_rows, dim, out);
+    if (dim % 32 == 0)
+        hipLaunchKernelGGL(l2_sqnorm_coalesced_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, table, n_rows, dim, out);
+    else
+        hipLaunchKernelGGL(l2_sqnorm_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table,
+                           n_rows, dim, out);
     return ph_launch_status();
 }
 

@@ -222,3 +222,12 @@ def test_compact_matches(device):
         assert int(out["n_match"][b]) == n
         for k in ("x1", "y1", "x2", "y2", "match_q", "match_t"):
             assert np.array_equal(out[k][b, :n].cpu().numpy(), ref[k][:n])
+
+
+@pytest.mark.parametrize("rows,dim", [(1, 128), (63, 128), (1000, 128), (4097, 64), (300, 36)])
+def test_row_sqnorm_bit_exact(device, rows, dim):
+    """Natural-order fma chain, bit for bit; dims that are a multiple of 32 take the coalesced kernel."""
+    rng = np.random.default_rng(rows + dim)
+    a = rng.standard_normal((rows, dim)).astype(np.float32)
+    got = matching.row_sqnorm(_t(a[None], device)).cpu().numpy()[0]
+    assert np.array_equal(got.view(np.uint32), orc.row_sqnorm(a).view(np.uint32))
