@@ -197,6 +197,17 @@ int ph_triangulate(const float* P1, const float* P2,
                    const int32_t* n_valid, const uint64_t* mask,
                    int B, int C, int N, float* XYZ, int32_t* front, void* stream);
 
+/* Glue of the batched two-view pipeline (no reference counterpart; SURVEY.md §8e "pose table"):
+ * ph_gather_models copies hypothesis sel[b] (NULL = 0) of every item's [H][stride] block to out [B][stride];
+ * ph_pose_table picks the cheirality winner win[b] = argmax_c front[b][c] (first maximum; win may be NULL) among
+ * the C candidate projections P2 [B][C][12] = [R | t] and writes the pose-table row the ranks gather:
+ * R (9, row-major) | t (3) | inliers | matches | winning hypothesis | status (1 if inliers >= min_inliers). */
+int ph_gather_models(const float* models, const int32_t* sel, int B, int H, int stride,
+                     float* out, void* stream);
+int ph_pose_table(const float* P2, const int32_t* front, int C,
+                  const int32_t* best_count, const int32_t* n_match, const int32_t* best_idx,
+                  int B, int min_inliers, float* table, int32_t* win, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (4) Board-pose helpers: the reference's own arithmetic, batched.
  * ------------------------------------------------------------------------------------------ */

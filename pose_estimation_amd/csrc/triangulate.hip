@@ -140,6 +140,44 @@ __global__ __launch_bounds__(256) void compact_kernel(const int32_t* __restrict_
     if (tid == 0) n_match[b] = base;
 }
 
+// models[b][sel[b]][0..stride) -> out[b][0..stride): the winning hypothesis of every item in one small launch
+__global__ __launch_bounds__(256) void gather_models_kernel(const float* __restrict__ models, const int32_t* __restrict__ sel,
+                                                           int B, int H, int stride, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * stride) return;
+    const int b = i / stride, e = i - b * stride;
+    const int h = sel ? min(max(sel[b], 0), H - 1) : 0;
+    out[i] = models[((size_t)b * H + h) * stride + e];
+}
+
+// Cheirality winner and pose-table row of every item: win = argmax_c front[b][c] (first maximum), table row =
+// R (9, row-major) | t (3) of P2[b][win] = [R | t], inliers, matches, winning hypothesis, status.
+__global__ __launch_bounds__(64) void pose_table_kernel(const float* __restrict__ P2, const int32_t* __restrict__ front, int C,
+                                                       const int32_t* __restrict__ best_count,
+                                                       const int32_t* __restrict__ n_match,
+                                                       const int32_t* __restrict__ best_idx, int B, int min_inliers,
+                                                       float* __restrict__ table, int32_t* __restrict__ win) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    int w = 0, best = front[(size_t)b * C];
+    for (int c = 1; c < C; ++c) {
+        const int f = front[(size_t)b * C + c];
+        if (f > best) { best = f; w = c; }
+    }
+    const float* P = P2 + ((size_t)b * C + w) * 12;
+    float* o = table + (size_t)b * 16;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[3 * r] = P[4 * r]; o[3 * r + 1] = P[4 * r + 1]; o[3 * r + 2] = P[4 * r + 2];
+        o[9 + r] = P[4 * r + 3];
+    }
+    o[12] = (float)best_count[b];
+    o[13] = (float)n_match[b];
+    o[14] = (float)best_idx[b];
+    o[15] = best_count[b] >= min_inliers ? 1.0f : 0.0f;
+    if (win) win[b] = w;
+}
+
 }  // namespace
 
 extern "C" int ph_triangulate(const float* P1, const float* P2, const float* x1, const float* y1, const float* x2,
@@ -168,5 +206,24 @@ extern "C" int ph_compact_matches(const int32_t* idx, const int32_t* keep, const
     if (!ph_aligned(kp_q, 8) || !ph_aligned(kp_t, 8)) return PH_ERR_INVALID_ARG;
     hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, idx, keep, (const float2*)kp_q,
                        (const float2*)kp_t, view_q, view_t, nq, nt, x1, y1, x2, y2, match_q, match_t, n_match);
+    return ph_launch_status();
+}
+
+extern "C" int ph_gather_models(const float* models, const int32_t* sel, int B, int H, int stride, float* out, void* stream) {
+    if (B < 0 || H < 1 || stride < 1) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!models || !out) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(gather_models_kernel, dim3(ph_ceil_div(B * stride, 256)), dim3(256), 0, (hipStream_t)stream, models, sel,
+                       B, H, stride, out);
+    return ph_launch_status();
+}
+
+extern "C" int ph_pose_table(const float* P2, const int32_t* front, int C, const int32_t* best_count, const int32_t* n_match,
+                             const int32_t* best_idx, int B, int min_inliers, float* table, int32_t* win, void* stream) {
+    if (B < 0 || C < 1) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!P2 || !front || !best_count || !n_match || !best_idx || !table) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(pose_table_kernel, dim3(ph_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, P2, front, C, best_count,
+                       n_match, best_idx, B, min_inliers, table, win);
     return ph_launch_status();
 }

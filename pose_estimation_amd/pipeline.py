@@ -25,8 +25,6 @@ from . import geometry, matching, ransac, triangulation
 STATUS_OK = 1.0
 STATUS_DEGENERATE = 0.0
 
-_R_COLS = [0, 1, 2, 4, 5, 6, 8, 9, 10]
-_T_COLS = [3, 7, 11]
 
 
 @dataclass
@@ -66,7 +64,7 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_essential(E_hyp, bi, *pts, thr_sq, m["n_match"])
     B = E_hyp.shape[0]
-    E_best = E_hyp[torch.arange(B, device=E_hyp.device), bi.long()]
+    E_best = ransac.gather_models(E_hyp, bi)
     host = torch.empty((B, 9), dtype=torch.float32, pin_memory=True)
     host.copy_(E_best, non_blocking=True)
     ev = torch.cuda.Event()
@@ -84,19 +82,11 @@ def relative_pose_back(f: Front):
     P2d = torch.from_numpy(P2).to(dev, non_blocking=True)
     xyz, front = triangulation.triangulate(P1d, P2d, *f.pts, n_valid=f.n_match, mask=f.mask,
                                            want_points=f.want_points, want_front=True)
-    win = torch.argmax(front, dim=1)
-    Pw = P2d[torch.arange(B, device=dev), win]                     # [B, 12] = rows of [R | t]
-    table = torch.empty((B, 16), dtype=torch.float32, device=dev)
-    table[:, :9] = Pw[:, _R_COLS]
-    table[:, 9:12] = Pw[:, _T_COLS]
-    table[:, 12] = f.best_count.float()
-    table[:, 13] = f.n_match.float()
-    table[:, 14] = f.best_idx.float()
-    table[:, 15] = torch.where(f.best_count >= 5, STATUS_OK, STATUS_DEGENERATE)
+    table, win = triangulation.pose_table(P2d, front, f.best_count, f.n_match, f.best_idx, min_inliers=5)
     out = dict(table=table, E_hyp=f.E_hyp, n_match=f.n_match, best_idx=f.best_idx, best_count=f.best_count,
                mask=f.mask, front=front, win=win)
     if f.want_points:
-        out["xyz"] = xyz[torch.arange(B, device=dev), win]
+        out["xyz"] = xyz[torch.arange(B, device=dev), win.long()]
         out["pts"] = f.pts
     return out
 

@@ -76,6 +76,17 @@ def solve_p3p(X, Y, Z, u, v, samples, K4=None, want_counts=False):
     return (P, ns) if want_counts else P
 
 
+def gather_models(models, sel):
+    """models ``[B, H, stride]`` float32, sel int32 ``[B]`` -> ``[B, stride]``: hypothesis sel[b] of every item."""
+    lib = L.load()
+    models = L.dev(models, torch.float32, "models")
+    B, H, stride = models.shape
+    sel = L.opt_i32(sel, B, "sel")
+    out = torch.empty((B, stride), dtype=torch.float32, device=models.device)
+    L.check(lib.ph_gather_models(L.ptr(models), L.ptr(sel), B, H, stride, L.ptr(out), L.stream_ptr()), "ph_gather_models")
+    return out
+
+
 def pose_from_projection(P, sel=None, K4=None):
     """(rvec, tvec) float64 ``[B, 6]`` of hypothesis sel[b] of each item's ``[H, 12]`` block (K [R|t] when K4 is given)."""
     lib = L.load()

@@ -34,3 +34,19 @@ def triangulate(P1, P2, x1, y1, x2, y2, n_valid=None, mask=None, want_points=Tru
     L.check(lib.ph_triangulate(L.ptr(P1), L.ptr(P2), *(L.ptr(a) for a in pts), L.ptr(n_valid), L.ptr(mask),
                                B, Cn, N, L.ptr(XYZ), L.ptr(front), L.stream_ptr()), "ph_triangulate")
     return XYZ, front
+
+
+def pose_table(P2, front, best_count, n_match, best_idx, min_inliers=5):
+    """Cheirality winner + pose-table rows.  P2 ``[B, C, 12]`` f32, front int32 ``[B, C]``; returns
+    (table ``[B, 16]`` f32, win int32 ``[B]``)."""
+    lib = L.load()
+    P2 = L.dev(P2, torch.float32, "P2")
+    B, C = P2.shape[0], P2.shape[1]
+    front = L.dev(front, torch.int32, "front")
+    best_count, n_match, best_idx = (L.opt_i32(t, B, n) for t, n in ((best_count, "best_count"), (n_match, "n_match"),
+                                                                      (best_idx, "best_idx")))
+    table = torch.empty((B, 16), dtype=torch.float32, device=P2.device)
+    win = torch.empty((B,), dtype=torch.int32, device=P2.device)
+    L.check(lib.ph_pose_table(L.ptr(P2), L.ptr(front), C, L.ptr(best_count), L.ptr(n_match), L.ptr(best_idx), B,
+                              int(min_inliers), L.ptr(table), L.ptr(win), L.stream_ptr()), "ph_pose_table")
+    return table, win

@@ -76,3 +76,31 @@ def test_cheirality_vote_picks_true_candidate(device):
     Rc, tc = cands[true_c]
     assert np.allclose(Rc, R, atol=1e-6) and np.dot(tc, t / np.linalg.norm(t)) > 0.999
     assert front[true_c] == sel[:nv].sum()
+
+
+def test_gather_models_and_pose_table(device):
+    """The pipeline's glue kernels against their torch formulation: hypothesis gather, first-maximum cheirality
+    winner, pose-table row layout (R row-major 9 | t 3 | inliers | matches | hypothesis | status)."""
+    import torch
+    from pose_estimation_amd import ransac
+    rng = np.random.default_rng(4)
+    B, H, C = 37, 50, 4
+    models = torch.from_numpy(rng.standard_normal((B, H, 9)).astype(np.float32)).to(device)
+    sel = torch.from_numpy(rng.integers(0, H, B).astype(np.int32)).to(device)
+    got = ransac.gather_models(models, sel)
+    assert torch.equal(got, models[torch.arange(B, device=device), sel.long()])
+    P2 = torch.from_numpy(rng.standard_normal((B, C, 12)).astype(np.float32)).to(device)
+    front = torch.from_numpy(rng.integers(0, 6, (B, C)).astype(np.int32)).to(device)     # small range: plenty of ties
+    bc = torch.from_numpy(rng.integers(0, 12, B).astype(np.int32)).to(device)
+    nm = torch.from_numpy(rng.integers(0, 9000, B).astype(np.int32)).to(device)
+    bidx = torch.from_numpy(rng.integers(0, 4100, B).astype(np.int32)).to(device)
+    table, win = triangulation.pose_table(P2, front, bc, nm, bidx, min_inliers=5)
+    f = front.cpu().numpy()
+    want_win = np.array([int(np.flatnonzero(r == r.max())[0]) for r in f])
+    assert np.array_equal(win.cpu().numpy(), want_win)
+    Pw = P2.cpu().numpy()[np.arange(B), want_win]
+    t = table.cpu().numpy()
+    assert np.array_equal(t[:, :9], Pw[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]]) and np.array_equal(t[:, 9:12], Pw[:, [3, 7, 11]])
+    assert np.array_equal(t[:, 12], bc.cpu().numpy().astype(np.float32)) and np.array_equal(t[:, 13], nm.cpu().numpy().astype(np.float32))
+    assert np.array_equal(t[:, 14], bidx.cpu().numpy().astype(np.float32))
+    assert np.array_equal(t[:, 15], (bc.cpu().numpy() >= 5).astype(np.float32))
