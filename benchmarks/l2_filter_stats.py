@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pose_estimation_amd import _lib as L, matching, synthetic
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 kind = sys.argv[2] if len(sys.argv) > 2 else "random"
+prec = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda:0")
 n = 8192
 if kind == "random":
@@ -22,10 +23,10 @@ else:
 vq = torch.arange(0, 2 * P, 2, dtype=torch.int32, device=dev); vt = vq + 1
 nrm = matching.row_sqnorm(tab)
 lib = L.load()
-wsb = lib.ph_match_l2_ws_bytes(P, n, n, 128, 1)
+wsb = lib.ph_match_l2_ws_bytes(P, n, n, 128, prec)
 ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
 idx = torch.empty((P, n), dtype=torch.int32, device=dev); d1 = torch.empty((P, n), device=dev); d2 = torch.empty_like(d1)
-L.check(lib.ph_match_l2_top2(L.ptr(tab), L.ptr(tab), L.ptr(nrm), L.ptr(nrm), L.ptr(vq), L.ptr(vt), None, None, P, n, n, 128, 1,
+L.check(lib.ph_match_l2_top2(L.ptr(tab), L.ptr(tab), L.ptr(nrm), L.ptr(nrm), L.ptr(vq), L.ptr(vt), None, None, P, n, n, 128, prec,
                              L.ptr(idx), L.ptr(d1), L.ptr(d2), L.ptr(ws), wsb, L.stream_ptr()), "l2")
 torch.cuda.synchronize()
 off = (P * 4 + 255) // 256 * 256
