@@ -31,7 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kTR = 32;       // train rows per tile
-constexpr int kQT = 2;        // 32-query column tiles per wave
+constexpr int kQT = 2;        // 32-query column tiles per wave (1: 3 waves per SIMD, measured 20 % slower)
 constexpr int kDim = 128;
 constexpr int kCPR = kDim / 8;  // 16-byte bf16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
+__global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_filter_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
@@ -177,16 +177,18 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
         if (tid < kTR) { ((float*)tnl[buf])[tid] = stage_tn; ((float*)tnl2[buf])[tid] = stage_tn; }
     };
 
-    auto tile_scores = [&](int buf, f32x16& acc0, f32x16& acc1) {
+    auto tile_scores = [&](int buf, f32x16 (&acc)[kQT]) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 z = tnl[buf][2 * g + h];      // rows 8g + 4h .. +3
-            acc0[4 * g + 0] = z.x; acc0[4 * g + 1] = z.y; acc0[4 * g + 2] = z.z; acc0[4 * g + 3] = z.w;
+            acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
         }
+        if (kQT > 1) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {                  // a second LDS read instead of 16 register copies
-            const float4 z = tnl2[buf][2 * g + h];
-            acc1[4 * g + 0] = z.x; acc1[4 * g + 1] = z.y; acc1[4 * g + 2] = z.z; acc1[4 * g + 3] = z.w;
+            for (int g = 0; g < 4; ++g) {              // a second LDS read instead of 16 register copies
+                const float4 z = tnl2[buf][2 * g + h];
+                acc[kQT - 1][4 * g + 0] = z.x; acc[kQT - 1][4 * g + 1] = z.y; acc[kQT - 1][4 * g + 2] = z.z; acc[kQT - 1][4 * g + 3] = z.w;
+            }
         }
         const uint4* rh = &tile_hi[buf][li * kCPR];
         const uint4* rl = &tile_lo[buf][li * kCPR];
@@ -200,12 +202,12 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
                 nl = rl[(2 * s + 2 + h) ^ (li & 15)];
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the two reads above the MFMAs (the scheduler would sink them)
-            acc0 = mfma_bf16(ah, bh[0][s], acc0);
-            acc1 = mfma_bf16(ah, bh[1][s], acc1);
-            acc0 = mfma_bf16(al, bh[0][s], acc0);
-            acc1 = mfma_bf16(al, bh[1][s], acc1);
-            acc0 = mfma_bf16(ah, bl[0][s], acc0);
-            acc1 = mfma_bf16(ah, bl[1][s], acc1);
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_bf16(ah, bh[ct][s], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_bf16(al, bh[ct][s], acc[ct]);
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_bf16(ah, bl[ct][s], acc[ct]);
             ah = nh; al = nl;
         }
     };
@@ -263,11 +265,11 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
         __syncthreads();
         if (it + 1 < n_iter) commit(cur ^ 1);
         if (it + 2 < n_iter) fetch(tile_row0(it + 2));
-        f32x16 acc0, acc1;
-        tile_scores(cur, acc0, acc1);
+        f32x16 acc[kQT];
+        tile_scores(cur, acc);
         if (priming) {
-            prime(acc0, 0);
-            prime(acc1, 1);
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
             if (it + 1 == n_prime) {
 #pragma unroll
                 for (int ct = 0; ct < kQT; ++ct) {
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(WAVES * 64, 8 / WAVES) void l2_filter_kernel(
                 }
             }
         } else {
-            filter(acc0, 0, t0);
-            filter(acc1, 1, t0);
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0);
         }
         cur ^= 1;
     }
@@ -495,8 +497,8 @@ constexpr int kWaves = 4;     // 256 queries per block
 
 L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
     L2FilterPlan p;
-    const long blocks = (long)B * ph_ceil_div(nq, kWaves * 64);
-    int s = (int)((256 * (8 / kWaves) + blocks - 1) / blocks);   // 8 waves per CU
+    const long blocks = (long)B * ph_ceil_div(nq, kWaves * 32 * kQT);
+    int s = (int)((256 * ((kQT == 1 ? 12 : 8) / kWaves) + blocks - 1) / blocks);   // fill every CU once
     const int max_s = ph_ceil_div(nt, 32 * kTR);                // at least 32 tiles per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -521,7 +523,7 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
     int2* list = (int2*)((char*)ws + p.off_list);
     hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, view_t, n_t, nq, nt, p.slots, tmax, cnt);
     if (nt > 0) {
-        const int nqb = ph_ceil_div(nq, kWaves * 64);
+        const int nqb = ph_ceil_div(nq, kWaves * 32 * kQT);
         const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
         hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, desc_t, view_q, view_t, n_q, n_t,
                            nq, nt, p.rows_per_split, norm_t, norm_q, tmax, cnt, list, p.slots, nqb, B);
