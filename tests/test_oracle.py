@@ -155,3 +155,37 @@ def test_summary_grades():
     assert orc.summary_of_means([1.0, 1.5])["grade"] == "GOOD"
     assert orc.summary_of_means([2.0, 4.0])["grade"] == "FAIR"
     assert orc.summary_of_means([5.0])["grade"] == "POOR"
+
+
+def test_p3p_oracle_recovers_pose_and_solutions_check():
+    """The NumPy P3P checker (np.roots + Kabsch): on noise-free samples every solution reprojects the three points
+    onto their bearings with positive depth, and the true pose is among them."""
+    from oracle import p3p as op
+    rng = np.random.default_rng(7)
+    R = synthetic.rot_y(np.deg2rad(20.0)) @ synthetic.rot_x(np.deg2rad(-10.0)); t = np.array([0.1, -0.2, 4.0])
+    found = 0
+    for _ in range(100):
+        X = rng.uniform(-1, 1, (3, 3))
+        Y = X @ R.T + t
+        f = Y / np.linalg.norm(Y, axis=1, keepdims=True)
+        sols = op.solve_p3p(X, f)
+        assert 1 <= len(sols) <= 4
+        for Rs, ts in sols:
+            orth, det, depth, mism = op.check_solution(Rs, ts, X, f)
+            assert orth < 1e-9 and abs(det - 1) < 1e-9 and depth > 0 and mism < 1e-7
+        found += any(np.abs(Rs - R).max() < 1e-6 and np.abs(ts - t).max() < 1e-6 for Rs, ts in sols)
+    assert found >= 97
+
+
+def test_lm_oracle_converges_to_truth_on_board_views():
+    """The NumPy LM checker of ph_refine_pose_lm: from a perturbed start it returns to the true board pose
+    (noise-free corners -> rms ~ 0) and lands in the EXCELLENT band with 0.3 px corner noise."""
+    for noise, tol_rms in ((0.0, 1e-4), (0.3, 1.0)):   # f32 corner coordinates bound the noise-free residual
+        v = synthetic.board_views(1, seed=5, noise_px=noise)[0]
+        obj = orc.board_object_points()[v["ids"].flatten()].reshape(-1, 3)
+        img = np.concatenate([c.reshape(4, 2) for c in v["corners"]])
+        p_true = np.concatenate([orc.rodrigues_inv(v["R"]), v["t"]])
+        p0 = p_true + np.array([0.04, -0.03, 0.05, 0.02, -0.01, 0.03])
+        p, rms = orc.refine_pose_lm_np(obj, img, p0, max_iters=100)
+        assert rms < tol_rms
+        assert np.abs(p - p_true).max() < (1e-6 if noise == 0.0 else 2e-3)
