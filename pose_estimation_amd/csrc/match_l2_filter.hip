@@ -306,13 +306,13 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
     return acc;
 }
 
-// Re-rank: 16 lanes per query, four queries per wave.  The kernel is a chain of dependent memory round trips, so it is
+// Re-rank: 8 lanes per query, eight queries per wave.  The kernel is a chain of dependent memory round trips, so it is
 // organised to make them few and wide: (1) the wave's four query rows go to LDS once; (2) every lane reads its list
 // entries of all segments at once and the query's final bound (second-largest listed sA - 2e) is formed by shuffles;
-// (3) the surviving entries of all four queries (2-3 each) are compacted into a wave queue in LDS; (4) the queued rows
+// (3) the surviving entries of all eight queries (2-3 each) are compacted into a wave queue in LDS; (4) the queued rows
 // are fetched whole, 16 at a time, by all 64 lanes (coalesced 512-byte rows, swizzled into LDS) and lane r runs the
 // exact fma chain of row r out of LDS; (5) lane 0 of each query folds the results into (best, runner-up).
-constexpr int kRL = 16;
+constexpr int kRL = 8;
 constexpr int kRQ = 64 / kRL;          // queries per wave
 constexpr int kRC = 16;                // rows per fetch chunk
 struct RerankLds {
@@ -358,21 +358,25 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         __builtin_amdgcn_wave_barrier();
     };
 
-    // (1) query rows -> LDS: lane (qid, sl) copies chunks sl and sl + 16 of its query
-    L.qrow[qid * 32 + sl] = q[sl];
-    L.qrow[qid * 32 + sl + 16] = q[sl + 16];
+    // (1) query rows -> LDS: lane (qid, sl) copies chunks sl, sl + kRL, ... of its query
+#pragma unroll
+    for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + c] = q[c];
 
-    // (2) list entries of this lane (entries sl and sl + 16 of every segment) and the final bound
+    // (2) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound
     bool overflow = false;
     float p1 = -INFINITY, p2 = -INFINITY;
     if (live)
         for (int slot = 0; slot < slots; ++slot) {
             const int c = cnt[o * slots + slot];
-            const int2 e0 = list[(o * slots + slot) * kCapH + sl];        // issued together with the count
             overflow |= c > kCapH;
-            if (sl < c) { const float v = __int_as_float(e0.y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
-            if (sl + 16 < c) {                                            // second cache line of the segment: rarely used
-                const float v = __int_as_float(list[(o * slots + slot) * kCapH + sl + 16].y);
+            int2 e[16 / kRL];                                             // first cache line of the segment (16 entries):
+#pragma unroll
+            for (int k = 0; k < 16 / kRL; ++k) e[k] = list[(o * slots + slot) * kCapH + sl + kRL * k];   // issued with the count
+#pragma unroll
+            for (int k = 0; k < 16 / kRL; ++k)
+                if (sl + kRL * k < c) { const float v = __int_as_float(e[k].y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
+            for (int k = sl + 16; k < c && k < kCapH; k += kRL) {         // second cache line: rarely used
+                const float v = __int_as_float(list[(o * slots + slot) * kCapH + k].y);
                 p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v);
             }
         }
@@ -437,13 +441,12 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     for (int w = 32; w > 0; w >>= 1) max_slots = max(max_slots, __shfl_xor(max_slots, w));
     wave_sync();
     for (int slot = 0; slot < max_slots; ++slot) {
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < kCapH / kRL; ++pass) {
             int j = -1;
             if (live && !overflow) {
                 const int c = min(cnt[o * slots + slot], kCapH);
-                if (sl + 16 * pass < c) {
-                    const int2 e = list[(o * slots + slot) * kCapH + sl + 16 * pass];
+                if (sl + kRL * pass < c) {
+                    const int2 e = list[(o * slots + slot) * kCapH + sl + kRL * pass];
                     if (__int_as_float(e.y) >= bound) j = e.x;
                 }
             }
