@@ -177,10 +177,10 @@ def main():
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                     "traffic": None, "launch_ms": kern_ms, "algorithmic_flops_per_launch": flops}
     else:
-        # One ph_match_l2_top2 call = l2_filter_prep_kernel + l2_filter_kernel<4> + l2_rerank_kernel; the events bracket
+        # One ph_match_l2_top2 call = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel; the events bracket
         # the call.  `achieved` counts the ALGORITHMIC 2*N*M*D flops per pair; the filter executes 3 bf16 MFMA products
         # per algorithmic product (+3 % priming), so its ceiling on this scale is a third of the bf16 peak.
-        roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
+        roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
                     "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_BF16_MFMA_TFLOPS,
                     # HBM bytes per launch of 16 pairs, rocprofv3 --pmc offline (profiles/r1/l2_filter_pmc_summary.json):

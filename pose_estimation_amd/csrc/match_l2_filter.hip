@@ -86,20 +86,65 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
     if (tid == 0) tmax[b] = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+// Train tile image, written once per (pair, tile) and streamed by every query block of the pair straight into LDS
+// (global_load_lds: no registers, no VALU, no LDS write instructions in the filter loop).  It is the LDS image itself:
+//   uint4 [0, 512)     leading bf16 terms, chunk p of row r at r*16 + (p ^ (r & 15))
+//   uint4 [512, 1024)  second bf16 terms, same order
+//   uint4 [1024, 1040) -|t|^2/2 of the 32 rows as f32, twice (-inf for rows at or beyond the pair's valid count)
+constexpr int kImg = 2 * kTR * kCPR + 16;     // uint4 per tile image
+__global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restrict__ dt, const float* __restrict__ tnorm,
+                                                         const int32_t* __restrict__ view_t, const int32_t* __restrict__ n_t,
+                                                         int nt, int tiles, uint4* __restrict__ img) {
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+    const int vt = view_t ? view_t[b] : b;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const float4* T = (const float4*)(dt + (size_t)vt * nt * kDim);
+    uint4* out = img + (size_t)blockIdx.x * kImg;
+    const int t0 = tile * kTR;
+#pragma unroll
+    for (int u = 0; u < kTR * kCPR / 256; ++u) {
+        const int id = tid + 256 * u, row = id / kCPR, p = id % kCPR;
+        const bool ok = t0 + row < ntv;
+        const float4* src = T + (size_t)(t0 + row) * (kDim / 4) + 2 * p;
+        const float4 a = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 c = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 hi, lo;
+        split8(a, c, hi, lo);
+        out[row * kCPR + (p ^ (row & 15))] = hi;
+        out[kTR * kCPR + row * kCPR + (p ^ (row & 15))] = lo;
+    }
+    if (tid < 2 * kTR) {
+        const int row = tid & (kTR - 1);
+        ((float*)(out + 2 * kTR * kCPR))[tid] = (t0 + row < ntv) ? -0.5f * tnorm[(size_t)vt * nt + t0 + row] : -INFINITY;
+    }
+}
+
+// One LDS-DMA instruction: every active lane copies 16 bytes from its own global address to LDS byte address
+// lds_dst + 16 * lane (lds_dst wave-uniform, passed in M0).  Written as asm on purpose: the compiler drains a DMA it
+// knows about (vmcnt(0)) in front of the next LDS read of any address, which would serialise copy and MFMA chain; the
+// completion is waited for by hand at the one place that needs it.  An asm load is absent from the compiler's own
+// vmcnt bookkeeping, which only makes its waits for its own (older or younger) loads more conservative.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_filter_kernel(
-    const float* __restrict__ dq, const float* __restrict__ dt,
+    const float* __restrict__ dq, const uint4* __restrict__ img, int tiles,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int rows_per_split,
-    const float* __restrict__ tnorm, const float* __restrict__ qnorm, const float* __restrict__ tmax,
+    const float* __restrict__ qnorm, const float* __restrict__ tmax,
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
-    constexpr int STG = kTR * kCPR / NT;          // 8-float groups staged per thread per tile
-    __shared__ uint4 tile_hi[2][kTR * kCPR];
-    __shared__ uint4 tile_lo[2][kTR * kCPR];
-    __shared__ float4 tnl[2][kTR / 4];
-    __shared__ float4 tnl2[2][kTR / 4];           // same values: the second column tile's C operand is read, not copied
+    static_assert(WAVES == 4, "the staging below deals 16 one-KB slices and a 256-byte tail to four waves");
+    __shared__ uint4 smem[2 * kImg];              // two tile images; ONE array: a second LDS object beside an LDS-DMA
+                                                  // target makes the compiler drain the DMA before every LDS read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -115,14 +160,12 @@ __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_fi
     }
     const int split = rr / nqb, xb = rr % nqb;
     const int vq = view_q ? view_q[b] : b;
-    const int vt = view_t ? view_t[b] : b;
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
     const float* Q = dq + (size_t)vq * nq * kDim;
-    const float4* T = (const float4*)(dt + (size_t)vt * nt * kDim);
-    const float* TN = tnorm + (size_t)vt * nt;
     const float* QN = qnorm + (size_t)vq * nq;
     const float Tm = tmax[b];
+    const uint4* IMG = img + (size_t)b * tiles * kImg;
 
     const int qw0 = xb * (NT / 64) * (32 * kQT) + wave * (32 * kQT);   // first query of this wave
 
@@ -152,46 +195,35 @@ __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_fi
     const int n_tiles = (t_end - t_begin + kTR - 1) / kTR;
     const int n_prime = min(8, max(1, n_tiles / 16));
 
-    float4 stage[2 * STG];
-    float stage_tn = 0.0f;
-    auto fetch = [&](int t0) {
+    // tile image -> LDS buffer: wave w copies KB slices w, w+4, w+8, w+12 and 64 bytes of the tail, asynchronously
+    auto stage = [&](int tile, int buf) {
+        const uint4* src = IMG + (size_t)tile * kImg;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + wave * 64));
 #pragma unroll
-        for (int u = 0; u < STG; ++u) {
-            const int id = tid + NT * u, row = id / kCPR, p = id % kCPR;
-            const bool ok = t0 + row < t_end;
-            const float4* src = T + (size_t)(t0 + row) * (kDim / 4) + 2 * p;
-            stage[2 * u] = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
-            stage[2 * u + 1] = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (tid < kTR) stage_tn = (t0 + tid < t_end) ? -0.5f * TN[t0 + tid] : -INFINITY;
-    };
-    auto commit = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < STG; ++u) {
-            const int id = tid + NT * u, row = id / kCPR, p = id % kCPR;
-            uint4 hi, lo;
-            split8(stage[2 * u], stage[2 * u + 1], hi, lo);
-            tile_hi[buf][row * kCPR + (p ^ (row & 15))] = hi;
-            tile_lo[buf][row * kCPR + (p ^ (row & 15))] = lo;
-        }
-        if (tid < kTR) { ((float*)tnl[buf])[tid] = stage_tn; ((float*)tnl2[buf])[tid] = stage_tn; }
+        for (int u = 0; u < 4; ++u) glds16(src + (wave + 4 * u) * 64 + lane, dst + 4096u * u);
+        const unsigned dst_tail = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + 1024 + wave * 4));
+        if (lane < 4) glds16(src + 1024 + wave * 4 + lane, dst_tail);
     };
 
     auto tile_scores = [&](int buf, f32x16 (&acc)[kQT]) {
+        const uint4* tile_hi = smem + buf * kImg;
+        const uint4* tile_lo = tile_hi + kTR * kCPR;
+        const float4* tnl = (const float4*)(tile_hi + 2 * kTR * kCPR);
+        const float4* tnl2 = tnl + kTR / 4;           // same values: the second column tile's C operand is read, not copied
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 z = tnl[buf][2 * g + h];      // rows 8g + 4h .. +3
+            const float4 z = tnl[2 * g + h];           // rows 8g + 4h .. +3
             acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
         }
         if (kQT > 1) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {              // a second LDS read instead of 16 register copies
-                const float4 z = tnl2[buf][2 * g + h];
+                const float4 z = tnl2[2 * g + h];
                 acc[kQT - 1][4 * g + 0] = z.x; acc[kQT - 1][4 * g + 1] = z.y; acc[kQT - 1][4 * g + 2] = z.z; acc[kQT - 1][4 * g + 3] = z.w;
             }
         }
-        const uint4* rh = &tile_hi[buf][li * kCPR];
-        const uint4* rl = &tile_lo[buf][li * kCPR];
+        const uint4* rh = &tile_hi[li * kCPR];
+        const uint4* rl = &tile_lo[li * kCPR];
         // A fragments one k-step ahead in registers: the LDS latency of step s+1 hides under the six MFMAs of step s
         uint4 ah = rh[h ^ (li & 15)], al = rl[h ^ (li & 15)];
 #pragma unroll
@@ -250,23 +282,24 @@ __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_fi
         thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
     };
 
-    // Staging pipeline, one barrier per tile: at the top of iteration `it` tile `it` is in LDS buffer `cur` (written
-    // during the previous iteration) and the registers hold tile it+1.  After the barrier the registers are split and
-    // written into the other buffer and the loads of tile it+2 are issued — all of it next to this tile's MFMA chain.
+    // Staging pipeline, one barrier per tile.  At the top of iteration `it` every wave has waited for its own share of
+    // tile `it` (the wait sits behind the previous MFMA chain, ahead of that iteration's list stores, so it never waits
+    // for a store) and the barrier makes the whole image visible; the copy of tile it+1 into the other buffer is
+    // issued right behind the barrier and lands during this tile's MFMA chain.
     const int n_iter = n_prime + n_tiles;
-    auto tile_row0 = [&](int it) { return t_begin + (it < n_prime ? it : it - n_prime) * kTR; };
-    fetch(tile_row0(0));
-    commit(0);
-    if (n_iter > 1) fetch(tile_row0(1));
+    auto tile_of = [&](int it) { return t_begin / kTR + (it < n_prime ? it : it - n_prime); };
+    stage(tile_of(0), 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int cur = 0;
     for (int it = 0; it < n_iter; ++it) {
         const bool priming = it < n_prime;
-        const int t0 = tile_row0(it);
-        __syncthreads();
-        if (it + 1 < n_iter) commit(cur ^ 1);
-        if (it + 2 < n_iter) fetch(tile_row0(it + 2));
+        const int t0 = tile_of(it) * kTR;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (it + 1 < n_iter) stage(tile_of(it + 1), cur ^ 1);
         f32x16 acc[kQT];
         tile_scores(cur, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (priming) {
 #pragma unroll
             for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
@@ -513,7 +546,9 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
     p.slots = 2 * p.splits;
     p.off_cnt = ((size_t)B * sizeof(float) + 255) / 256 * 256;
     p.off_list = p.off_cnt + ((size_t)B * nq * p.slots * sizeof(int32_t) + 255) / 256 * 256;
-    p.total = p.off_list + (size_t)B * nq * p.slots * kCapH * sizeof(int2);
+    p.tiles = ph_ceil_div(nt, kTR);
+    p.off_img = p.off_list + ((size_t)B * nq * p.slots * kCapH * sizeof(int2) + 255) / 256 * 256;
+    p.total = p.off_img + (size_t)B * p.tiles * kImg * sizeof(uint4);
     return p;
 }
 
@@ -524,12 +559,15 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
     float* tmax = (float*)ws;
     int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
     int2* list = (int2*)((char*)ws + p.off_list);
+    uint4* img = (uint4*)((char*)ws + p.off_img);
     hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, view_t, n_t, nq, nt, p.slots, tmax, cnt);
     if (nt > 0) {
+        hipLaunchKernelGGL(l2_presplit_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, desc_t, norm_t, view_t, n_t,
+                           nt, p.tiles, img);
         const int nqb = ph_ceil_div(nq, kWaves * 32 * kQT);
         const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
-        hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, desc_t, view_q, view_t, n_q, n_t,
-                           nq, nt, p.rows_per_split, norm_t, norm_q, tmax, cnt, list, p.slots, nqb, B);
+        hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, img, p.tiles, view_q, view_t, n_q, n_t,
+                           nq, nt, p.rows_per_split, norm_q, tmax, cnt, list, p.slots, nqb, B);
     }
     const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
     hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
