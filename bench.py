@@ -6,7 +6,8 @@ descriptors (dim 128) per view, 4096 RANSAC essential-matrix hypotheses per pair
 one pass of the hot path over a batch of --pairs such pairs per GPU, inputs resident in HBM:
 
     row norms -> L2 top-2 (fp32 MFMA) -> ratio test -> compaction -> Philox minimal samples ->
-    5-point solver (hypothesis generation) -> Sampson scoring of H hypotheses -> best -> inlier mask -> [host: 3x3 SVD decomposition] -> 4-candidate
+    5-point solver (hypothesis generation) -> Sampson scoring of H hypotheses -> best -> inlier mask ->
+    decomposition of the winning E (closed form on the device; --decompose host = NumPy SVD) -> 4-candidate
     triangulation + cheirality vote -> pose table  (-> all_gather of the table when N > 1)
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
@@ -83,6 +84,12 @@ def main():
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
                          "1 = bf16x3 MFMA candidate filter + exact f32 re-rank")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the batches alternate over: with 2, the latency-bound RANSAC stages of one batch "
+                         "run beside the MFMA-bound matcher of the next")
+    ap.add_argument("--decompose", default="device", choices=["device", "host"],
+                    help="where the winning E is decomposed into its (R, t) candidates: closed form on the device "
+                         "(no host round trip) or NumPy SVD on the host")
     ap.add_argument("--check", action="store_true", help="verify pose accuracy of the last step against ground truth")
     args = ap.parse_args()
 
@@ -119,7 +126,8 @@ def main():
 
     def front():
         return pipeline.relative_pose_front(match, batch["kp_q"], batch["kp_t"], None, None, None, thr_sq,
-                                            n_samples=N_SAMPLES, seed=max(state["step"], 0) + 1000)
+                                            n_samples=N_SAMPLES, seed=max(state["step"], 0) + 1000,
+                                            decompose=args.decompose)
 
     def back(f):
         out = pipeline.relative_pose_back(f)
@@ -127,19 +135,27 @@ def main():
             dist.all_gather_into_tensor(gathered, out["table"])
         return out
 
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream()]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+
     def run(n_steps, timed):
         """n_steps whole batches.  The front half of batch k+1 is enqueued before the host finishes batch k
         (its 3x3 SVDs), so the GPU does not idle during the host round trip; every batch is completed
-        (pose table written, gathered) inside the call."""
+        (pose table written, gathered) inside the call.  Batch k lives on stream k mod --streams."""
         pending, out = None, None
         for k in range(n_steps):
             state["step"] = k if timed else -1
-            f = front()
+            st = streams[k % len(streams)]
+            with torch.cuda.stream(st):
+                f = front()
             if pending is not None:
-                out = back(pending)
-            pending = f
+                with torch.cuda.stream(pending[1]):
+                    out = back(pending[0])
+            pending = (f, st)
         if pending is not None:
-            out = back(pending)
+            with torch.cuda.stream(pending[1]):
+                out = back(pending[0])
         return out
 
     def barrier():
@@ -199,7 +215,7 @@ def main():
             "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
                                    "4096 essential-matrix hypotheses per pair", "pairs_per_step_per_gpu": P,
                        "features": N_FEAT, "dim": DIM, "hypotheses": N_HYP, "ratio": 0.75, "threshold_px": THR_PX,
-                       "minimal_samples": N_SAMPLES,
+                       "minimal_samples": N_SAMPLES, "streams": args.streams, "decompose": args.decompose,
                        "hypothesis_source": "generated in the timed region: Philox minimal samples of the pair's own matches -> device 5-point solver (10 slots per sample)",
                        "parallelism": f"pairs sharded over {world} rank(s), final all_gather of the [pairs,16] pose table"},
             "hyps_per_sec": world * P * N_HYP * args.steps / dt,

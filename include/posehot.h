@@ -204,6 +204,14 @@ int ph_triangulate(const float* P1, const float* P2,
  * R (9, row-major) | t (3) | inliers | matches | winning hypothesis | status (1 if inliers >= min_inliers). */
 int ph_gather_models(const float* models, const int32_t* sel, int B, int H, int stride,
                      float* out, void* stream);
+/* ph_decompose_essential: the recoverPose-style decomposition of hypothesis sel[b] (NULL = 0) of every item's
+ * [H][9] block of essential matrices into its four (R, t) candidates, on the device (closed form, float64; no
+ * reference counterpart — north_star leaves this step on the host, where pose_estimation_amd.geometry does it by
+ * SVD; this entry point removes the host round trip from the batched pipeline).  P2 [B][4][12] = [R | t] in the
+ * order (Ra, t), (Ra, -t), (Rb, t), (Rb, -t), |t| = 1; P1 [B][4][12] (may be NULL) is filled with [I | 0].
+ * The candidate SET equals the SVD construction's; their order and the sign of t are this function's own. */
+int ph_decompose_essential(const float* E, const int32_t* sel, int B, int H,
+                           float* P1, float* P2, void* stream);
 int ph_pose_table(const float* P2, const int32_t* front, int C,
                   const int32_t* best_count, const int32_t* n_match, const int32_t* best_idx,
                   int B, int min_inliers, float* table, int32_t* win, void* stream);

@@ -72,10 +72,17 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
     const int p_end = min(nv, p_begin + pts_per_split);
 
     // the wave's hypotheses stay in registers for the whole kernel (tail waves re-score H-1)
+    // An all-zero model (the solvers' empty solution slot) passes neither test for any point (0 < 0, w > 0): its
+    // count is 0 by the contract's own arithmetic, so its residual tests are skipped (wave-uniform branch).
     float m[kHPW][NP];
+    bool live[kHPW];
 #pragma unroll
     for (int k = 0; k < kHPW; ++k) {
         const float* mb = models + ((size_t)b * H + min(h0 + k, H - 1)) * NP;
+        uint32_t any = 0;
+#pragma unroll
+        for (int e = 0; e < NP; ++e) any |= __float_as_uint(mb[e]) << 1;      // +-0 -> 0
+        live[k] = __builtin_amdgcn_readfirstlane(any) != 0u;
 #pragma unroll
         for (int e = 0; e < NP; ++e) {
             m[k][e] = mb[e];
@@ -101,6 +108,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
         }
 #pragma unroll
         for (int k = 0; k < kHPW; ++k) {
+            if (!live[k]) continue;
 #pragma unroll
             for (int p = 0; p < kPPL; ++p) cnt[k] += __popcll(__ballot(Model::test(m[k], pt[p], thr_sq)));
         }

@@ -178,7 +178,76 @@ __global__ __launch_bounds__(64) void pose_table_kernel(const float* __restrict_
     if (win) win[b] = w;
 }
 
+// The four (R, t) candidates of an essential matrix E ~ [t]x R in closed form (B. K. P. Horn, "Recovering baseline and
+// orientation from essential matrix", 1990), float64, one thread per item:
+//   t t' = tr(EE')/2 I - EE'   -> t from its row of largest diagonal (sign: that diagonal entry positive)
+//   R    = (Cof(E) -+ [t]x E) / |t|^2,   Cof(E) rows = cross products of the other two rows of E
+// Candidates in the order (Ra, t), (Ra, -t), (Rb, t), (Rb, -t), t unit; P2 = [R | t], P1 = [I | 0].  An E that is not
+// an essential matrix to working precision gives R that is not orthonormal to the same degree (the 5-point solver's
+// E are essential to f32 rounding); an all-zero E gives R = I, t = 0.
+__global__ __launch_bounds__(64) void decompose_essential_kernel(const float* __restrict__ models, const int32_t* __restrict__ sel,
+                                                                int B, int H, float* __restrict__ P1, float* __restrict__ P2) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int h = sel ? min(max(sel[b], 0), H - 1) : 0;
+    const float* src = models + ((size_t)b * H + h) * 9;
+    double E[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E[i][j] = (double)src[3 * i + j];
+    double G[3][3];                                   // EE'
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G[i][j] = E[i][0] * E[j][0] + E[i][1] * E[j][1] + E[i][2] * E[j][2];
+    const double half_tr = 0.5 * (G[0][0] + G[1][1] + G[2][2]);
+    double T[3][3];                                   // t t'
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T[i][j] = (i == j ? half_tr : 0.0) - G[i][j];
+    int r = 0;
+    if (T[1][1] > T[r][r]) r = 1;
+    if (T[2][2] > T[r][r]) r = 2;
+    double R[2][3][3], t[3];
+    if (T[r][r] > 0.0) {
+        const double inv = 1.0 / sqrt(T[r][r]);
+        double tb[3] = {T[r][0] * inv, T[r][1] * inv, T[r][2] * inv};       // |tb|^2 = tr(EE')/2 up to rounding
+        const double n2 = tb[0] * tb[0] + tb[1] * tb[1] + tb[2] * tb[2];
+        const double in2 = 1.0 / n2, in1 = 1.0 / sqrt(n2);
+        for (int i = 0; i < 3; ++i) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+            for (int j = 0; j < 3; ++j) {
+                const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+                const double cof = E[i1][j1] * E[i2][j2] - E[i1][j2] * E[i2][j1];
+                const double txe = tb[i1] * E[i2][j] - tb[i2] * E[i1][j];        // ([t]x E)[i][j]
+                R[0][i][j] = (cof - txe) * in2;
+                R[1][i][j] = (cof + txe) * in2;
+            }
+            t[i] = tb[i] * in1;
+        }
+    } else {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) R[0][i][j] = R[1][i][j] = (i == j) ? 1.0 : 0.0;
+            t[i] = 0.0;
+        }
+    }
+    for (int c = 0; c < 4; ++c) {
+        float* p2 = P2 + ((size_t)b * 4 + c) * 12;
+        const double sg = (c & 1) ? -1.0 : 1.0;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) p2[4 * i + j] = (float)R[c >> 1][i][j];
+            p2[4 * i + 3] = (float)(sg * t[i]);
+        }
+        if (P1) {
+            float* p1 = P1 + ((size_t)b * 4 + c) * 12;
+            for (int e = 0; e < 12; ++e) p1[e] = (e == 0 || e == 5 || e == 10) ? 1.0f : 0.0f;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ph_decompose_essential(const float* E, const int32_t* sel, int B, int H, float* P1, float* P2, void* stream) {
+    if (B < 0 || H < 1) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!E || !P2) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(decompose_essential_kernel, dim3(ph_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, E, sel, B, H, P1, P2);
+    return ph_launch_status();
+}
 
 extern "C" int ph_triangulate(const float* P1, const float* P2, const float* x1, const float* y1, const float* x2,
                               const float* y2, const int32_t* n_valid, const uint64_t* mask, int B, int C, int N,

@@ -3,14 +3,16 @@
     match (L2 or Hamming, top-2) -> Lowe ratio test -> compact correspondences
       -> Philox minimal samples -> 5-point solver (hypotheses) -> score H hypotheses
       -> best hypothesis -> inlier mask                                         [front, device]
-      -> decompose the winning E into its 4 (R, t) candidates                   [host, 3x3 SVDs]
+      -> decompose the winning E into its 4 (R, t) candidates                   [device, or host 3x3 SVDs]
       -> triangulate with all 4 + cheirality vote -> pose table row             [back, device]
 
 The reference's per-image loop (main.py:163-214) is what gets batched: one launch per stage
-handles B pairs; the only host round trip is the 3x3 SVD per pair that north_star leaves on
-the host (recoverPose-style decomposition).  The pipeline is split at that round trip into
-`relative_pose_front` / `relative_pose_back` so a caller can enqueue the next batch's front
-before finishing the previous batch's back: the GPU then never waits for the host.
+handles B pairs.  north_star leaves the recoverPose-style decomposition on the host; with
+``decompose="host"`` the pipeline does exactly that (3x3 SVD per pair, one host round trip) and
+is split at the round trip into `relative_pose_front` / `relative_pose_back`, so a caller can
+enqueue the next batch's front before finishing the previous batch's back.  The default
+``decompose="device"`` uses the closed-form device decomposition (`ph_decompose_essential`)
+instead: the whole batch is then one chain of launches with no host synchronisation at all.
 Output: a [B, 16] float32 pose table (R row-major 9, t 3, inliers, matches, winning hypothesis,
 status) — the unit that is gathered across ranks.
 """
@@ -36,15 +38,15 @@ class Front:
     best_idx: torch.Tensor
     best_count: torch.Tensor
     mask: torch.Tensor
-    E_best_host: torch.Tensor
-    copied: torch.cuda.Event
+    E_best_host: torch.Tensor            # None with decompose="device"
+    copied: torch.cuda.Event             # None with decompose="device"
     want_points: bool = False
     extra: dict = field(default_factory=dict)
 
 
 def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
-                        n_samples=410, seed=0) -> Front:
-    """Everything up to the inlier mask, plus an asynchronous copy of the winning E of every pair.
+                        n_samples=410, seed=0, decompose="device") -> Front:
+    """Everything up to the inlier mask, plus (decompose="host") an asynchronous copy of the winning E of every pair.
 
     match: callable returning (idx, d1, d2, kind) with kind "l2" or "hamming",
            e.g. ``lambda: (*matching.match_l2(...), "l2")``.
@@ -63,6 +65,10 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"])
     bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_essential(E_hyp, bi, *pts, thr_sq, m["n_match"])
+    if decompose == "device":
+        return Front(pts, m["n_match"], E_hyp, bi, bc, mask, None, None, want_points)
+    if decompose != "host":
+        raise ValueError("decompose must be 'device' or 'host'")
     B = E_hyp.shape[0]
     E_best = ransac.gather_models(E_hyp, bi)
     host = torch.empty((B, 9), dtype=torch.float32, pin_memory=True)
@@ -73,13 +79,17 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
 
 
 def relative_pose_back(f: Front):
-    """Host decomposition of the winning E matrices, 4-candidate triangulation + cheirality vote, pose table."""
-    f.copied.synchronize()
-    B = f.E_best_host.shape[0]
-    P1, P2, _, _ = geometry.candidate_projections(f.E_best_host.numpy().reshape(B, 3, 3))
+    """Decomposition of the winning E matrices (on the host when the front copied them there, else on the device),
+    4-candidate triangulation + cheirality vote, pose table."""
     dev = f.E_hyp.device
-    P1d = torch.from_numpy(P1).to(dev, non_blocking=True)
-    P2d = torch.from_numpy(P2).to(dev, non_blocking=True)
+    B = f.E_hyp.shape[0]
+    if f.E_best_host is None:
+        P1d, P2d = ransac.decompose_essential(f.E_hyp, f.best_idx)
+    else:
+        f.copied.synchronize()
+        P1, P2, _, _ = geometry.candidate_projections(f.E_best_host.numpy().reshape(B, 3, 3))
+        P1d = torch.from_numpy(P1).to(dev, non_blocking=True)
+        P2d = torch.from_numpy(P2).to(dev, non_blocking=True)
     xyz, front = triangulation.triangulate(P1d, P2d, *f.pts, n_valid=f.n_match, mask=f.mask,
                                            want_points=f.want_points, want_front=True)
     table, win = triangulation.pose_table(P2d, front, f.best_count, f.n_match, f.best_idx, min_inliers=5)
@@ -92,11 +102,11 @@ def relative_pose_back(f: Front):
 
 
 def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
-                        n_samples=410, seed=0):
+                        n_samples=410, seed=0, decompose="device"):
     """front + back for one batch of B pairs.  Returns dict(table [B,16] device f32, n_match, best_idx,
     best_count, mask, E_hyp, front, win and, with want_points, xyz / pts)."""
     return relative_pose_back(relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio,
-                                                  want_points, n_samples, seed))
+                                                  want_points, n_samples, seed, decompose))
 
 
 def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096, seed=0, refine=True, max_iters=20):

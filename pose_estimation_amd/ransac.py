@@ -87,6 +87,24 @@ def gather_models(models, sel):
     return out
 
 
+def decompose_essential(E, sel=None):
+    """The four (R, t) candidates of hypothesis sel[b] of each item's ``[H, 9]`` block, on the device.
+
+    Returns (P1, P2) float32 ``[B, 4, 12]``: P1 = [I | 0], P2 = [R | t] in the order (Ra, t), (Ra, -t), (Rb, t),
+    (Rb, -t).  Device counterpart of ``geometry.candidate_projections`` (same candidate set, own order)."""
+    lib = L.load()
+    E = L.dev(E, torch.float32, "E")
+    if E.dim() != 3 or E.shape[2] != 9:
+        raise ValueError("E must be [B, H, 9]")
+    B, H = E.shape[0], E.shape[1]
+    sel = L.opt_i32(sel, B, "sel")
+    P1 = torch.empty((B, 4, 12), dtype=torch.float32, device=E.device)
+    P2 = torch.empty((B, 4, 12), dtype=torch.float32, device=E.device)
+    L.check(lib.ph_decompose_essential(L.ptr(E), L.ptr(sel), B, H, L.ptr(P1), L.ptr(P2), L.stream_ptr()),
+            "ph_decompose_essential")
+    return P1, P2
+
+
 def pose_from_projection(P, sel=None, K4=None):
     """(rvec, tvec) float64 ``[B, 6]`` of hypothesis sel[b] of each item's ``[H, 12]`` block (K [R|t] when K4 is given)."""
     lib = L.load()

@@ -25,14 +25,15 @@ def _best_pose_err(E9, R, t):
     return min(geometry.rotation_angle_deg(Rc[0, c], R) + geometry.direction_angle_deg(tc[0, c], t) for c in range(4))
 
 
-def test_pipeline_matches_cpu_path_with_identical_samples(device):
+@pytest.mark.parametrize("decompose", ["device", "host"])
+def test_pipeline_matches_cpu_path_with_identical_samples(device, decompose):
     n, S, seed = 2048, 120, 4242
     scs = [synthetic.two_view_pair(n=n, seed=100 + b) for b in range(2)]
     dq = _t(np.stack([s["desc1"] for s in scs]), device); dt = _t(np.stack([s["desc2"] for s in scs]), device)
     kq = _t(np.stack([s["kp1"] for s in scs]), device); kt = _t(np.stack([s["kp2"] for s in scs]), device)
     thr_sq = np.float32((1.0 / synthetic.FX) ** 2)
     out = pipeline.relative_pose_batch(lambda: (*matching.match_l2(dq, dt), "l2"), kq, kt, None, None, None,
-                                       float(thr_sq), n_samples=S, seed=seed, want_points=True)
+                                       float(thr_sq), n_samples=S, seed=seed, want_points=True, decompose=decompose)
     table = out["table"].cpu().numpy()
     E_gpu = out["E_hyp"].cpu().numpy()
     mask_gpu = out["mask"].cpu().numpy().view(np.uint64)
@@ -95,3 +96,35 @@ def test_pipeline_with_hamming_matcher_and_given_hypotheses(device):
     assert tab[13] > 1000 and tab[12] > 0.8 * tab[13]
     assert geometry.rotation_angle_deg(tab[:9].reshape(3, 3), R) < 0.5
     assert geometry.direction_angle_deg(tab[9:12], t) < 1.0
+
+
+def test_device_decomposition_equals_svd_candidates(device):
+    """ph_decompose_essential: same four (R, t) candidates as the host's SVD construction (as a set), R orthonormal
+    to f32 rounding of E, selection by sel, the all-zero matrix degenerates to (I, 0)."""
+    rng = np.random.default_rng(77)
+    B, H = 300, 3
+    E = np.zeros((B, H, 9), np.float32)
+    truth = []
+    for b in range(B):
+        R = synthetic.rot_x(rng.uniform(-3, 3)) @ synthetic.rot_y(rng.uniform(-3, 3)) @ synthetic.rot_x(rng.uniform(-3, 3))
+        t = rng.normal(size=3)
+        e = synthetic.essential_from_pose(R, t)
+        e = e / np.linalg.norm(e) * (1.0 if b % 2 else -1.0)
+        E[b] = rng.normal(size=(H, 9))
+        E[b, b % H] = e.reshape(9).astype(np.float32)
+        truth.append(E[b, b % H].astype(np.float64).reshape(3, 3))
+    E[B - 1] = 0.0
+    sel = (np.arange(B) % H).astype(np.int32)
+    P1, P2 = ransac.decompose_essential(_t(E, device), _t(sel, device))
+    P1, P2 = P1.cpu().numpy().reshape(B, 4, 3, 4), P2.cpu().numpy().reshape(B, 4, 3, 4)
+    eye = np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1)
+    assert np.array_equal(P1, np.broadcast_to(eye, P1.shape).astype(np.float32))
+    for b in range(B - 1):
+        Rs, ts = geometry.decompose_essential(truth[b][None])
+        for c in range(4):
+            R, t = P2[b, c, :, :3].astype(np.float64), P2[b, c, :, 3].astype(np.float64)
+            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-6 and abs(np.linalg.det(R) - 1.0) < 1e-6
+            assert min(max(np.abs(R - Rs[0, k]).max(), np.abs(t - ts[0, k]).max()) for k in range(4)) < 1e-6
+        assert np.array_equal(P2[b, 0, :, :3], P2[b, 1, :, :3]) and np.array_equal(P2[b, 0, :, 3], -P2[b, 1, :, 3])
+        assert np.array_equal(P2[b, 2, :, :3], P2[b, 3, :, :3]) and not np.allclose(P2[b, 0, :, :3], P2[b, 2, :, :3])
+    assert np.array_equal(P2[B - 1], np.broadcast_to(eye, (4, 3, 4)).astype(np.float32))
