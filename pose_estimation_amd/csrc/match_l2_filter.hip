@@ -1,25 +1,31 @@
-// match_l2_filter.hip — the squared-L2 matcher as "bf16x3 candidate filter + exact f32 re-rank".
+// match_l2_filter.hip — the squared-L2 matcher as "fp16 candidate filter + exact f32 re-rank".
 // Same contract and bit-identical outputs as the f32 MFMA kernel of match_l2.hip; the
-// matrix work runs on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) and only a handful of
-// candidates per query are re-evaluated with the contract's f32 fma chain.
+// matrix work runs on v_mfma_f32_32x32x16_f16 (16x the f32 MFMA rate, ONE product per algorithmic product) and
+// only a handful of candidates per query are re-evaluated with the contract's f32 fma chain.
 //
-// Filter.  Every f32 descriptor element x is split into two bf16 terms, x = xh + xl + xr with
-// |xr| <= 2^-16 |x|, and the score  s = q.t - |t|^2/2  is approximated by
-//     sA = -|t|^2/2 + sum_k (th*qh + tl*qh + th*ql)            (three bf16 MFMA products, f32 accumulate)
-// The dropped terms (tl*ql, tr*q, t*qr) are bounded by 3.1*2^-16 * sum|t_k||q_k|, the f32 accumulation of the
-// MFMAs and the rounding of the contract's own chain by a few 2^-20 of the same sum, so
-//     |sA - s| <= e_i := 2^-13 * (|q_i| * Tmax + Tmax^2 / 2),      Tmax = max_j |t_j|  of the pair's train view.
+// Filter.  Per pair, the train rows and the query rows are scaled by powers of two st, sq that bring the largest
+// row norm of either side into [2^14, 2^15) (exact in f32; every element then lies inside fp16's normal range down
+// to 2^-29 of the largest norm), rounded to fp16 (nearest), and the score  s = q.t - |t|^2/2  is approximated by
+//     sA = sq*st * (-|t|^2/2) + sum_k fp16(sq*q_k) * fp16(st*t_k)        (fp16 products are exact in f32; f32 accumulate)
+// so sA ~ sq*st*s.  Error, in unscaled units: the two roundings contribute at most (2^-10 + 2^-22) sum|q_k||t_k|,
+// elements below fp16's normal range (flushed or not) at most 2^-24 Tmax (|q| + Qmax), the f32 accumulation of the
+// MFMAs and the rounding of the contract's own chain less than 2^-15 (|q||t| + |t|^2/2).  Hence
+//     |sA/(sq*st) - s| <= e_i := (2^-10 + 2^-13) (|q_i| Tmax + Tmax^2/2) + 2^-23 Tmax (|q_i| + Qmax),
+// Tmax, Qmax = largest row norm of the pair's train / query view.  (On SIFT-like unit-norm data the observed error is
+// a tenth of e_i; with three bf16 split products instead — the previous version of this file — the band was 2^-13
+// and the candidate count 9 instead of 11 per query, at three times the MFMA work.)
 // If a2 is ANY lower bound of the second-largest sA of the query (e.g. the second-largest seen so far by one
 // lane), both of the exact top-2 rows have sA >= a2 - 2 e_i: such rows are appended to a candidate list.  Every
 // (query, train split, lane half) owns a private list segment and counts in a register, so an append is one
-// fire-and-forget store: no atomics, nothing to wait for.  A short priming pass over the first tiles sets the bound before anything
-// is appended, so a query collects ~10 candidates out of 8192 rows.  A list entry is (row, sA).
+// fire-and-forget store: no atomics, nothing to wait for.  A short priming pass over the first tiles sets the bound
+// before anything is appended, so a query collects ~11 candidates out of 8192 rows.  A list entry is (row, sA).
 //
 // Re-rank.  l2_rerank_kernel first prunes the list with the FINAL bound (second-largest listed sA - 2 e_i: 2-3 rows
 // survive), then evaluates the contract's exact chain (k order 8c+{0,4,1,5,2,6,3,7}, start
 // -|t|^2/2) for the listed rows, takes (max s, lowest index on ties) and the runner-up, and writes idx/d1sq/d2sq
-// exactly as the f32 kernel does.  A list that overflowed its capacity (adversarially ordered input) makes the
-// query fall back to the exact chain over ALL rows inside the same kernel: slower, never wrong.
+// exactly as the f32 kernel does.  A list that overflowed its capacity (adversarially ordered input), or a pair whose
+// norms are so extreme that the scales leave f32's comfortable range, makes the query fall back to the exact chain
+// over ALL rows inside the same kernel: slower, never wrong.
 #include <math.h>
 
 #include "common.hpp"
@@ -27,36 +33,53 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTR = 32;       // train rows per tile
-constexpr int kQT = 2;        // 32-query column tiles per wave (1: 3 waves per SIMD, measured 20 % slower)
+constexpr int kTR = 32;       // train rows per MFMA tile
+constexpr int kSub = 2;       // MFMA tiles per staged tile (one barrier per staged tile)
+constexpr int kSR = kTR * kSub;   // train rows per staged tile
+constexpr int kQT = 2;        // 32-query column tiles per wave
 constexpr int kDim = 128;
-constexpr int kCPR = kDim / 8;  // 16-byte bf16 chunks per row
+constexpr int kCPR = kDim / 8;  // 16-byte fp16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
-constexpr float kEpsScale = 1.0f / 8192.0f;   // 2^-13
 constexpr int kCapH = 32;      // list entries per (query, split, lane half)
+constexpr int kBlocksPerCU = 2;
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+// ---- per-pair scales and the error band (one definition for the three kernels) -------------------------------------
+struct PairScale {
+    float sq, st, s;      // powers of two; s = sq * st
+    bool bad;             // norms too extreme for the scaled arithmetic: every query takes the exact path
+};
+__device__ __forceinline__ PairScale pair_scale(float Tmax, float Qmax) {
+    int et = 0, eq = 0;
+    if (Tmax > 0.0f) frexpf(Tmax, &et); else et = 15;
+    if (Qmax > 0.0f) frexpf(Qmax, &eq); else eq = 15;
+    const int kt = 15 - et, kq = 15 - eq;              // M < 2^e  ->  M * 2^(15-e) in [2^14, 2^15)
+    PairScale p;
+    p.bad = !(Tmax < INFINITY) || !(Qmax < INFINITY) || abs(kt) > 60 || abs(kq) > 60;
+    p.st = p.bad ? 1.0f : ldexpf(1.0f, kt);
+    p.sq = p.bad ? 1.0f : ldexpf(1.0f, kq);
+    p.s = p.sq * p.st;
+    return p;
+}
+// 2 e_i in scaled units
+__device__ __forceinline__ float band2_scaled(float qnorm_sq, float Tmax, float Qmax, float s) {
+    const float qn = sqrtf(qnorm_sq);
+    const float e = (1.0f / 1024.0f + 1.0f / 8192.0f) * (qn * Tmax + 0.5f * Tmax * Tmax) + (1.0f / 8388608.0f) * Tmax * (qn + Qmax);
+    return 2.0f * e * s;
 }
 
-// 8 consecutive f32 -> 8 bf16 leading terms + 8 bf16 second terms (x - hi is exact in f32)
-__device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi, uint4& lo) {
+// 8 consecutive f32, scaled by a power of two -> 8 fp16 (round to nearest even)
+__device__ __forceinline__ uint4 to_f16x8(const float4 a, const float4 b, float scale) {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    uint32_t h[4], l[4];
+    uint32_t h[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        h[p] = cvt_pk_bf16(x[2 * p], x[2 * p + 1]);
-        const float r0 = x[2 * p] - __uint_as_float(h[p] << 16);
-        const float r1 = x[2 * p + 1] - __uint_as_float(h[p] & 0xffff0000u);
-        l[p] = cvt_pk_bf16(r0, r1);
+        const _Float16 lo = (_Float16)(x[2 * p] * scale), hi = (_Float16)(x[2 * p + 1] * scale);
+        h[p] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
     }
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
+    return make_uint4(h[0], h[1], h[2], h[3]);
 }
 
 // max as plain C++, never inline asm: the operands are fresh MFMA results, and the compiler pads the MFMA -> VALU
@@ -64,58 +87,65 @@ __device__ __forceinline__ void split8(const float4 a, const float4 b, uint4& hi
 // reads stale registers).  This file is built with -fno-honor-nans, so fmaxf is a single v_max_f32.
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 
-__device__ __forceinline__ f32x16 mfma_bf16(const uint4 a, const uint4 b, const f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// zero the per-query slot counters of the launch and compute Tmax per pair
-__global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __restrict__ tnorm, const int32_t* __restrict__ view_t,
-                                                            const int32_t* __restrict__ n_t, int nq, int nt, int slots,
-                                                            float* __restrict__ tmax, int32_t* __restrict__ cnt) {
-    __shared__ float red[4];
+// zero the per-query slot counters of the launch and compute Tmax, Qmax per pair
+__global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __restrict__ tnorm, const float* __restrict__ qnorm,
+                                                            const int32_t* __restrict__ view_t, const int32_t* __restrict__ view_q,
+                                                            const int32_t* __restrict__ n_t, const int32_t* __restrict__ n_q,
+                                                            int nq, int nt, int slots, int B,
+                                                            float* __restrict__ tqmax, int32_t* __restrict__ cnt) {
+    __shared__ float red[2][4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int vt = view_t ? view_t[b] : b;
+    const int vt = view_t ? view_t[b] : b, vq = view_q ? view_q[b] : b;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const float* TN = tnorm + (size_t)vt * nt;
-    float m = 0.0f;
+    const float* QN = qnorm + (size_t)vq * nq;
+    float m = 0.0f, mq = 0.0f;
     for (int j = tid; j < ntv; j += 256) m = fmaxf(m, TN[j]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((tid & 63) == 0) red[tid >> 6] = m;
+    for (int j = tid; j < nqv; j += 256) mq = fmaxf(mq, QN[j]);
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = m; red[1][tid >> 6] = mq; }
     for (size_t i = tid; i < (size_t)nq * slots; i += 256) cnt[(size_t)b * nq * slots + i] = 0;
     __syncthreads();
-    if (tid == 0) tmax[b] = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+    if (tid < 2) tqmax[tid * B + b] = sqrtf(fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3])));
 }
 
-// Train tile image, written once per (pair, tile) and streamed by every query block of the pair straight into LDS
-// (global_load_lds: no registers, no VALU, no LDS write instructions in the filter loop).  It is the LDS image itself:
-//   uint4 [0, 512)     leading bf16 terms, chunk p of row r at r*16 + (p ^ (r & 15))
-//   uint4 [512, 1024)  second bf16 terms, same order
-//   uint4 [1024, 1040) -|t|^2/2 of the 32 rows as f32, twice (-inf for rows at or beyond the pair's valid count)
-constexpr int kImg = 2 * kTR * kCPR + 16;     // uint4 per tile image
+// Train tile image, written once per (pair, staged tile) and streamed by every query block of the pair straight into
+// LDS (global_load_lds: no registers, no VALU, no LDS write instructions in the filter loop).  It is the LDS image:
+//   uint4 [0, kSub*512)          scaled fp16 rows, MFMA tile after MFMA tile; chunk p of row r at r*16 + (p ^ (r & 15))
+//   then kSub*kQT*32 floats      sq*st*(-|t|^2/2) of the 32 rows of every MFMA tile, kQT copies each (one per column
+//                                tile: a second LDS address instead of register copies); -inf for rows at or beyond
+//                                the pair's valid count
+constexpr int kImgRows = kSub * kTR * kCPR;               // uint4
+constexpr int kImgTail = kSub * kQT * kTR / 4;            // uint4
+constexpr int kImg = kImgRows + kImgTail;                 // uint4 per staged tile image
 __global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restrict__ dt, const float* __restrict__ tnorm,
                                                          const int32_t* __restrict__ view_t, const int32_t* __restrict__ n_t,
-                                                         int nt, int tiles, uint4* __restrict__ img) {
+                                                         int nt, int tiles, int B, const float* __restrict__ tqmax,
+                                                         uint4* __restrict__ img) {
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
     const int vt = view_t ? view_t[b] : b;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const PairScale sc = pair_scale(tqmax[b], tqmax[B + b]);
     const float4* T = (const float4*)(dt + (size_t)vt * nt * kDim);
     uint4* out = img + (size_t)blockIdx.x * kImg;
-    const int t0 = tile * kTR;
+    const int t0 = tile * kSR;
 #pragma unroll
-    for (int u = 0; u < kTR * kCPR / 256; ++u) {
-        const int id = tid + 256 * u, row = id / kCPR, p = id % kCPR;
+    for (int u = 0; u < kImgRows / 256; ++u) {
+        const int id = tid + 256 * u, row = id / kCPR, p = id % kCPR;      // row within the staged tile
         const bool ok = t0 + row < ntv;
         const float4* src = T + (size_t)(t0 + row) * (kDim / 4) + 2 * p;
         const float4 a = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 c = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        uint4 hi, lo;
-        split8(a, c, hi, lo);
-        out[row * kCPR + (p ^ (row & 15))] = hi;
-        out[kTR * kCPR + row * kCPR + (p ^ (row & 15))] = lo;
+        out[row * kCPR + (p ^ (row & 15))] = to_f16x8(a, c, sc.st);
     }
-    if (tid < 2 * kTR) {
-        const int row = tid & (kTR - 1);
-        ((float*)(out + 2 * kTR * kCPR))[tid] = (t0 + row < ntv) ? -0.5f * tnorm[(size_t)vt * nt + t0 + row] : -INFINITY;
+    if (tid < kSub * kQT * kTR) {
+        const int sub = tid / (kQT * kTR), row = sub * kTR + (tid & (kTR - 1));
+        ((float*)(out + kImgRows))[tid] = (t0 + row < ntv) ? -0.5f * tnorm[(size_t)vt * nt + t0 + row] * sc.s : -INFINITY;
     }
 }
 
@@ -134,16 +164,16 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_filter_kernel(
+__global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     const float* __restrict__ dq, const uint4* __restrict__ img, int tiles,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int rows_per_split,
-    const float* __restrict__ qnorm, const float* __restrict__ tmax,
+    const float* __restrict__ qnorm, const float* __restrict__ tqmax,
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
-    static_assert(WAVES == 4, "the staging below deals 16 one-KB slices and a 256-byte tail to four waves");
-    __shared__ uint4 smem[2 * kImg];              // two tile images; ONE array: a second LDS object beside an LDS-DMA
+    static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256, "staging deal");
+    __shared__ uint4 smem[2 * kImg];              // two staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,13 +194,14 @@ __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_fi
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
     const float* Q = dq + (size_t)vq * nq * kDim;
     const float* QN = qnorm + (size_t)vq * nq;
-    const float Tm = tmax[b];
+    const float Tm = tqmax[b], Qm = tqmax[B + b];
+    const PairScale sc = pair_scale(Tm, Qm);
     const uint4* IMG = img + (size_t)b * tiles * kImg;
 
     const int qw0 = xb * (NT / 64) * (32 * kQT) + wave * (32 * kQT);   // first query of this wave
 
-    // B fragments: query row (qw0 + ct*32 + li), elements 16s + 8h .. +7, split into two bf16 terms
-    uint4 bh[kQT][kNS], bl[kQT][kNS];
+    // B fragments: query row (qw0 + ct*32 + li), elements 16s + 8h .. +7, scaled, as fp16
+    uint4 bh[kQT][kNS];
     float thr[kQT], eps2[kQT], a1[kQT], a2[kQT];
     size_t qoff[kQT];
     int nc[kQT];                                     // entries in this lane's private list segment
@@ -179,68 +210,54 @@ __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_fi
         const int qi = qw0 + ct * 32 + li;
         const float4* qrow = (const float4*)(Q + (size_t)min(qi, nq - 1) * kDim);
 #pragma unroll
-        for (int s = 0; s < kNS; ++s) split8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], bh[ct][s], bl[ct][s]);
+        for (int s = 0; s < kNS; ++s) bh[ct][s] = to_f16x8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], sc.sq);
         const bool live = qi < nqv;
         qoff[ct] = ((size_t)b * nq + min(qi, nq - 1)) * slots + (2 * split + h);
         nc[ct] = 0;
-        eps2[ct] = 2.0f * kEpsScale * (sqrtf(QN[min(qi, nq - 1)]) * Tm + 0.5f * Tm * Tm);
+        eps2[ct] = band2_scaled(QN[min(qi, nq - 1)], Tm, Qm, sc.s);
         thr[ct] = live ? -3.0e38f : INFINITY;           // finite floor: the -inf score of a padded row never reaches it;
                                                          // a dead lane never has a candidate
         a1[ct] = -INFINITY; a2[ct] = -INFINITY;
     }
 
-    const int t_begin = split * rows_per_split;
+    const int t_begin = split * rows_per_split;          // a multiple of kSR
     const int t_end = min(ntv, t_begin + rows_per_split);
     if (t_begin >= t_end) return;
-    const int n_tiles = (t_end - t_begin + kTR - 1) / kTR;
-    const int n_prime = min(8, max(1, n_tiles / 16));
+    const int n_tiles = (t_end - t_begin + kSR - 1) / kSR;
+    const int n_prime = min(8 / kSub, max(1, n_tiles / 16));
 
-    // tile image -> LDS buffer: wave w copies KB slices w, w+4, w+8, w+12 and 64 bytes of the tail, asynchronously
+    // staged tile -> LDS buffer: wave w copies KB slices w, w+4, ... and its share of the tail, asynchronously
     auto stage = [&](int tile, int buf) {
         const uint4* src = IMG + (size_t)tile * kImg;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + wave * 64));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) glds16(src + (wave + 4 * u) * 64 + lane, dst + 4096u * u);
-        const unsigned dst_tail = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + 1024 + wave * 4));
-        if (lane < 4) glds16(src + 1024 + wave * 4 + lane, dst_tail);
+        for (int u = 0; u < kImgRows / 256; ++u) glds16(src + (wave + 4 * u) * 64 + lane, dst + 4096u * u);
+        const unsigned dst_tail = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + kImgRows + wave * (kImgTail / 4)));
+        if (lane < kImgTail / 4) glds16(src + kImgRows + wave * (kImgTail / 4) + lane, dst_tail);
     };
 
-    auto tile_scores = [&](int buf, f32x16 (&acc)[kQT]) {
-        const uint4* tile_hi = smem + buf * kImg;
-        const uint4* tile_lo = tile_hi + kTR * kCPR;
-        const float4* tnl = (const float4*)(tile_hi + 2 * kTR * kCPR);
-        const float4* tnl2 = tnl + kTR / 4;           // same values: the second column tile's C operand is read, not copied
+    auto tile_scores = [&](int buf, int sub, f32x16 (&acc)[kQT]) {
+        const uint4* tile_hi = smem + buf * kImg + sub * (kTR * kCPR);
+        const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kQT * kTR / 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 z = tnl[2 * g + h];           // rows 8g + 4h .. +3
-            acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
-        }
-        if (kQT > 1) {
+        for (int ct = 0; ct < kQT; ++ct) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {              // a second LDS read instead of 16 register copies
-                const float4 z = tnl2[2 * g + h];
-                acc[kQT - 1][4 * g + 0] = z.x; acc[kQT - 1][4 * g + 1] = z.y; acc[kQT - 1][4 * g + 2] = z.z; acc[kQT - 1][4 * g + 3] = z.w;
+            for (int g = 0; g < 4; ++g) {
+                const float4 z = tnl[ct * (kTR / 4) + 2 * g + h];      // rows 8g + 4h .. +3
+                acc[ct][4 * g + 0] = z.x; acc[ct][4 * g + 1] = z.y; acc[ct][4 * g + 2] = z.z; acc[ct][4 * g + 3] = z.w;
             }
         }
         const uint4* rh = &tile_hi[li * kCPR];
-        const uint4* rl = &tile_lo[li * kCPR];
-        // A fragments one k-step ahead in registers: the LDS latency of step s+1 hides under the six MFMAs of step s
-        uint4 ah = rh[h ^ (li & 15)], al = rl[h ^ (li & 15)];
+        // A fragments one k-step ahead in registers: the LDS latency of step s+1 hides under the MFMAs of step s
+        uint4 ah = rh[h ^ (li & 15)];
 #pragma unroll
         for (int s = 0; s < kNS; ++s) {
-            uint4 nh = ah, nl = al;
-            if (s + 1 < kNS) {
-                nh = rh[(2 * s + 2 + h) ^ (li & 15)];
-                nl = rl[(2 * s + 2 + h) ^ (li & 15)];
-            }
-            __builtin_amdgcn_sched_barrier(0);      // keep the two reads above the MFMAs (the scheduler would sink them)
+            uint4 nh = ah;
+            if (s + 1 < kNS) nh = rh[(2 * s + 2 + h) ^ (li & 15)];
+            __builtin_amdgcn_sched_barrier(0);      // keep the read above the MFMAs (the scheduler would sink it)
 #pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_bf16(ah, bh[ct][s], acc[ct]);
-#pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_bf16(al, bh[ct][s], acc[ct]);
-#pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_bf16(ah, bl[ct][s], acc[ct]);
-            ah = nh; al = nl;
+            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(ah, bh[ct][s], acc[ct]);
+            ah = nh;
         }
     };
 
@@ -282,41 +299,44 @@ __global__ __launch_bounds__(WAVES * 64, (kQT == 1 ? 12 : 8) / WAVES) void l2_fi
         thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
     };
 
-    // Staging pipeline, one barrier per tile.  At the top of iteration `it` every wave has waited for its own share of
-    // tile `it` (the wait sits behind the previous MFMA chain, ahead of that iteration's list stores, so it never waits
-    // for a store) and the barrier makes the whole image visible; the copy of tile it+1 into the other buffer is
-    // issued right behind the barrier and lands during this tile's MFMA chain.
+    // Staging pipeline, one barrier per staged tile.  At the top of iteration `it` every wave has waited for its own
+    // share of tile `it` (the wait sits behind the previous MFMA chains, ahead of that iteration's last list stores, so
+    // it rarely waits for a store) and the barrier makes the whole image visible; the copy of tile it+1 into the other
+    // buffer is issued right behind the barrier and lands during this tile's MFMA chains.
     const int n_iter = n_prime + n_tiles;
-    auto tile_of = [&](int it) { return t_begin / kTR + (it < n_prime ? it : it - n_prime); };
+    auto tile_of = [&](int it) { return t_begin / kSR + (it < n_prime ? it : it - n_prime); };
     stage(tile_of(0), 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int cur = 0;
     for (int it = 0; it < n_iter; ++it) {
         const bool priming = it < n_prime;
-        const int t0 = tile_of(it) * kTR;
+        const int t0 = tile_of(it) * kSR;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (it + 1 < n_iter) stage(tile_of(it + 1), cur ^ 1);
-        f32x16 acc[kQT];
-        tile_scores(cur, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (priming) {
 #pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
-            if (it + 1 == n_prime) {
+        for (int sub = 0; sub < kSub; ++sub) {
+            f32x16 acc[kQT];
+            tile_scores(cur, sub, acc);
+            if (sub == kSub - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (priming) {
 #pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) {
-                    // second-largest of the union of the two halves' top-2, then restart the tracking: the primed
-                    // rows are seen again by the filtering pass
-                    const float o1 = __shfl_xor(a1[ct], 32), o2 = __shfl_xor(a2[ct], 32);
-                    const float second = fmaxf(fminf(a1[ct], o1), fmaxf(a2[ct], o2));
-                    thr[ct] = fmaxf(thr[ct], second - eps2[ct]);
-                    a1[ct] = -INFINITY; a2[ct] = -INFINITY;
-                }
+                for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0 + sub * kTR);
             }
-        } else {
+        }
+        if (it + 1 == n_prime) {
 #pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0);
+            for (int ct = 0; ct < kQT; ++ct) {
+                // second-largest of the union of the two halves' top-2, then restart the tracking: the primed
+                // rows are seen again by the filtering pass
+                const float o1 = __shfl_xor(a1[ct], 32), o2 = __shfl_xor(a2[ct], 32);
+                const float second = fmaxf(fminf(a1[ct], o1), fmaxf(a2[ct], o2));
+                thr[ct] = fmaxf(thr[ct], second - eps2[ct]);
+                a1[ct] = -INFINITY; a2[ct] = -INFINITY;
+            }
         }
         cur ^= 1;
     }
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t, int B, int nq, int nt,
     const float* __restrict__ tnorm, const float* __restrict__ qnorm,
-    const float* __restrict__ tmax, const int32_t* __restrict__ cnt, const int2* __restrict__ list, int slots,
+    const float* __restrict__ tqmax, const int32_t* __restrict__ cnt, const int2* __restrict__ list, int slots,
     int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq) {
     __shared__ RerankLds lds[4];
     // blocks of one pair share one residue of the block id mod 8 (one XCD, one L2 for the pair's train rows)
@@ -423,8 +443,10 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     // The two rows with the largest approximate scores are in the list (they passed every running bound), so the
     // second-largest LISTED sA is the query's true second-largest, and only rows with sA >= that - 2e can be one of
     // the exact top-2: typically 2-3 of the ~11 listed rows.
-    const float Tm = tmax[b];
-    const float bound = p2 - 2.0f * kEpsScale * (sqrtf(qnorm[(size_t)vq * nq + min(qi, nq - 1)]) * Tm + 0.5f * Tm * Tm);
+    const float Tm = tqmax[b], Qm = tqmax[B + b];
+    const PairScale sc = pair_scale(Tm, Qm);
+    const float bound = p2 - band2_scaled(qnorm[(size_t)vq * nq + min(qi, nq - 1)], Tm, Qm, sc.s);
+    overflow |= sc.bad;                                    // wave-uniform per pair: the lists of such a pair are not used
 
     float m1 = -INFINITY, m2 = -INFINITY;
     int32_t bi = PH_NO_INDEX;
@@ -534,19 +556,19 @@ constexpr int kWaves = 4;     // 256 queries per block
 L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
     L2FilterPlan p;
     const long blocks = (long)B * ph_ceil_div(nq, kWaves * 32 * kQT);
-    int s = (int)((256 * ((kQT == 1 ? 12 : 8) / kWaves) + blocks - 1) / blocks);   // fill every CU once
-    const int max_s = ph_ceil_div(nt, 32 * kTR);                // at least 32 tiles per split
+    int s = (int)((256 * kBlocksPerCU + blocks - 1) / blocks);   // fill every CU once
+    const int max_s = ph_ceil_div(nt, 32 * kSR);                // at least 32 staged tiles per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
-    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kTR) * kTR;
-    if (p.rows_per_split < kTR) p.rows_per_split = kTR;
+    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kSR) * kSR;
+    if (p.rows_per_split < kSR) p.rows_per_split = kSR;
     p.splits = ph_ceil_div(nt, p.rows_per_split);
     if (p.splits < 1) p.splits = 1;
     p.slots = 2 * p.splits;
-    p.off_cnt = ((size_t)B * sizeof(float) + 255) / 256 * 256;
+    p.tiles = ph_ceil_div(nt, kSR);
+    p.off_cnt = ((size_t)2 * B * sizeof(float) + 255) / 256 * 256;
     p.off_list = p.off_cnt + ((size_t)B * nq * p.slots * sizeof(int32_t) + 255) / 256 * 256;
-    p.tiles = ph_ceil_div(nt, kTR);
     p.off_img = p.off_list + ((size_t)B * nq * p.slots * kCapH * sizeof(int2) + 255) / 256 * 256;
     p.total = p.off_img + (size_t)B * p.tiles * kImg * sizeof(uint4);
     return p;
@@ -556,21 +578,22 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
                      const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
                      int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st) {
     const L2FilterPlan p = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
-    float* tmax = (float*)ws;
+    float* tqmax = (float*)ws;                                   // Tmax[B] | Qmax[B]
     int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
     int2* list = (int2*)((char*)ws + p.off_list);
     uint4* img = (uint4*)((char*)ws + p.off_img);
-    hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, view_t, n_t, nq, nt, p.slots, tmax, cnt);
+    hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, norm_q, view_t, view_q, n_t, n_q, nq, nt,
+                       p.slots, B, tqmax, cnt);
     if (nt > 0) {
         hipLaunchKernelGGL(l2_presplit_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, desc_t, norm_t, view_t, n_t,
-                           nt, p.tiles, img);
+                           nt, p.tiles, B, tqmax, img);
         const int nqb = ph_ceil_div(nq, kWaves * 32 * kQT);
         const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
         hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, img, p.tiles, view_q, view_t, n_q, n_t,
-                           nq, nt, p.rows_per_split, norm_q, tmax, cnt, list, p.slots, nqb, B);
+                           nq, nt, p.rows_per_split, norm_q, tqmax, cnt, list, p.slots, nqb, B);
     }
     const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
     hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
-                       view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tmax, cnt, list, p.slots, idx, d1sq, d2sq);
+                       view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tqmax, cnt, list, p.slots, idx, d1sq, d2sq);
     return ph_launch_status();
 }

@@ -7,9 +7,9 @@
 
 struct L2FilterPlan {
     int splits, rows_per_split, slots;
-    int tiles;                               // 32-row train tiles per pair
-    size_t off_cnt, off_list, off_img, total;   // workspace: Tmax[B] | entry counts [B][nq][slots] | candidate lists [B][nq][slots][32] of
-                                             // (row, approximate score), slots = 2 * splits | train tile images [B][tiles][16640 bytes]
+    int tiles;                               // staged train tiles per pair
+    size_t off_cnt, off_list, off_img, total;   // workspace: Tmax[B], Qmax[B] | entry counts [B][nq][slots] | candidate lists [B][nq][slots][32] of
+                                             // (row, approximate score), slots = 2 * splits | train tile images [B][tiles] (scaled fp16 rows + score presets)
 };
 L2FilterPlan plan_l2_filter(int B, int nq, int nt);
 int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm_q, const float* norm_t,
