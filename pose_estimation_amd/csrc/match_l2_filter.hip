@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
     static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256, "staging deal");
-    __shared__ uint4 smem[2 * kImg];              // two staged tiles; ONE array: a second LDS object beside an LDS-DMA
+    __shared__ uint4 smem[3 * kImg];              // ring of three staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,32 +299,41 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
     };
 
-    // Staging pipeline, one barrier per staged tile.  At the top of iteration `it` every wave has waited for its own
-    // share of tile `it` (the wait sits behind the previous MFMA chains, ahead of that iteration's last list stores, so
-    // it rarely waits for a store) and the barrier makes the whole image visible; the copy of tile it+1 into the other
-    // buffer is issued right behind the barrier and lands during this tile's MFMA chains.
+    // Staging pipeline: a ring of three LDS buffers, one barrier per staged tile, copies two tiles ahead.  At the top
+    // of iteration `it` every wave has waited for its own share of tile `it` and the barrier makes the whole image
+    // visible (and tells that everybody is done reading tile it-1, whose buffer the copy of tile it+2 now overwrites).
+    // The MFMA chains of all sub-tiles run first; then the wave waits for its share of tile it+1 — a counted wait that
+    // leaves the kGlds copies of tile it+2 in flight (the counter retires in issue order, and the list stores of the
+    // previous iteration are older than those copies) — and only then appends candidates, so no wait ever sees a
+    // young store.
+    constexpr int kGlds = kImgRows / 256 + 1;        // LDS-DMA instructions per wave per staged tile
+    static_assert(kGlds == 5, "the counted waits below are written for 5");
     const int n_iter = n_prime + n_tiles;
     auto tile_of = [&](int it) { return t_begin / kSR + (it < n_prime ? it : it - n_prime); };
     stage(tile_of(0), 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int cur = 0;
+    if (n_iter > 1) { stage(tile_of(1), 1); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int cur = 0, nxt2 = 2;
     for (int it = 0; it < n_iter; ++it) {
         const bool priming = it < n_prime;
         const int t0 = tile_of(it) * kSR;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (it + 1 < n_iter) stage(tile_of(it + 1), cur ^ 1);
+        const bool more = it + 2 < n_iter;
+        if (more) stage(tile_of(it + 2), nxt2);
+        f32x16 acc[kSub][kQT];
+#pragma unroll
+        for (int sub = 0; sub < kSub; ++sub) tile_scores(cur, sub, acc[sub]);
+        if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int sub = 0; sub < kSub; ++sub) {
-            f32x16 acc[kQT];
-            tile_scores(cur, sub, acc);
-            if (sub == kSub - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (priming) {
 #pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
+                for (int ct = 0; ct < kQT; ++ct) prime(acc[sub][ct], ct);
             } else {
 #pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0 + sub * kTR);
+                for (int ct = 0; ct < kQT; ++ct) filter(acc[sub][ct], ct, t0 + sub * kTR);
             }
         }
         if (it + 1 == n_prime) {
@@ -338,7 +347,8 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
                 a1[ct] = -INFINITY; a2[ct] = -INFINITY;
             }
         }
-        cur ^= 1;
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct)
