@@ -236,28 +236,35 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         if (lane < kImgTail / 4) glds16(src + kImgRows + wave * (kImgTail / 4) + lane, dst_tail);
     };
 
-    auto tile_scores = [&](int buf, int sub, f32x16 (&acc)[kQT]) {
-        const uint4* tile_hi = smem + buf * kImg + sub * (kTR * kCPR);
-        const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kQT * kTR / 4);
+    // All A fragments and score presets of a staged tile are read up front (the k-step of one fp16 product is only
+    // kQT MFMAs long: too short to hide an LDS read issued one step ahead), then the MFMA chains run back to back.
+    auto tile_scores = [&](int buf, f32x16 (&acc)[kSub][kQT]) {
+        uint4 af[kSub][kNS];
 #pragma unroll
-        for (int ct = 0; ct < kQT; ++ct) {
+        for (int sub = 0; sub < kSub; ++sub) {
+            const uint4* rh = smem + buf * kImg + sub * (kTR * kCPR) + li * kCPR;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 z = tnl[ct * (kTR / 4) + 2 * g + h];      // rows 8g + 4h .. +3
-                acc[ct][4 * g + 0] = z.x; acc[ct][4 * g + 1] = z.y; acc[ct][4 * g + 2] = z.z; acc[ct][4 * g + 3] = z.w;
+            for (int s = 0; s < kNS; ++s) af[sub][s] = rh[(2 * s + h) ^ (li & 15)];
+        }
+#pragma unroll
+        for (int sub = 0; sub < kSub; ++sub) {
+            const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kQT * kTR / 4);
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 z = tnl[ct * (kTR / 4) + 2 * g + h];      // rows 8g + 4h .. +3
+                    acc[sub][ct][4 * g + 0] = z.x; acc[sub][ct][4 * g + 1] = z.y; acc[sub][ct][4 * g + 2] = z.z; acc[sub][ct][4 * g + 3] = z.w;
+                }
             }
         }
-        const uint4* rh = &tile_hi[li * kCPR];
-        // A fragments one k-step ahead in registers: the LDS latency of step s+1 hides under the MFMAs of step s
-        uint4 ah = rh[h ^ (li & 15)];
 #pragma unroll
-        for (int s = 0; s < kNS; ++s) {
-            uint4 nh = ah;
-            if (s + 1 < kNS) nh = rh[(2 * s + 2 + h) ^ (li & 15)];
-            __builtin_amdgcn_sched_barrier(0);      // keep the read above the MFMAs (the scheduler would sink it)
+        for (int sub = 0; sub < kSub; ++sub) {
 #pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(ah, bh[ct][s], acc[ct]);
-            ah = nh;
+            for (int s = 0; s < kNS; ++s) {
+#pragma unroll
+                for (int ct = 0; ct < kQT; ++ct) acc[sub][ct] = mfma_f16(af[sub][s], bh[ct][s], acc[sub][ct]);
+            }
         }
     };
 
@@ -322,8 +329,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         const bool more = it + 2 < n_iter;
         if (more) stage(tile_of(it + 2), nxt2);
         f32x16 acc[kSub][kQT];
-#pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) tile_scores(cur, sub, acc[sub]);
+        tile_scores(cur, acc);
         if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
