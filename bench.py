@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
                          "1 = bf16x3 MFMA candidate filter + exact f32 re-rank")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the batches alternate over: with 2, the latency-bound RANSAC stages of one batch "
                          "run beside the MFMA-bound matcher of the next")
     ap.add_argument("--decompose", default="device", choices=["device", "host"],

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     uint4 bh[kQT][kNS];
     float thr[kQT], eps2[kQT], a1[kQT], a2[kQT];
     size_t qoff[kQT];
-    int nc[kQT];                                     // entries in this lane's private list segment
+    int2* lp[kQT];                                   // this lane's private list segment
+    int nc[kQT];                                     // entries in it
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct) {
         const int qi = qw0 + ct * 32 + li;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         for (int s = 0; s < kNS; ++s) bh[ct][s] = to_f16x8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], sc.sq);
         const bool live = qi < nqv;
         qoff[ct] = ((size_t)b * nq + min(qi, nq - 1)) * slots + (2 * split + h);
+        lp[ct] = list + qoff[ct] * kCapH;
         nc[ct] = 0;
         eps2[ct] = band2_scaled(QN[min(qi, nq - 1)], Tm, Qm, sc.s);
         thr[ct] = live ? -3.0e38f : INFINITY;           // finite floor: the -inf score of a padded row never reaches it;
@@ -281,9 +283,11 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     // reduced in four groups of four (v_max3); a group is entered only if some lane of the wave has a hit in it, so a
     // tile with one hit costs 1 + 4 wave-level tests and 4 masked blocks instead of 16.  thr only rises while rows are appended,
     // and every test uses the current value.
-    auto hit = [&](float v, int j, int ct) {
+    // A list entry is (row - 4h, sA): the row without the lane half's offset is wave-uniform (a scalar), and the half
+    // is implied by the segment the entry sits in (the re-rank adds it back).
+    auto hit = [&](float v, int jrow, int ct) {
         if (v >= thr[ct]) {
-            if (nc[ct] < kCapH) list[qoff[ct] * kCapH + nc[ct]] = make_int2(j, __float_as_int(v));
+            if (nc[ct] < kCapH) lp[ct][nc[ct]] = make_int2(jrow, __float_as_int(v));
             ++nc[ct];
             a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], v);
             a1[ct] = vmax(a1[ct], v);
@@ -296,12 +300,12 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) m4[i] = vmax(vmax(acc[4 * i], acc[4 * i + 1]), vmax(acc[4 * i + 2], acc[4 * i + 3]));
         if (!any_ge(vmax(vmax(m4[0], m4[1]), vmax(m4[2], m4[3])), ct)) return;
-        const int jb = t0 + 4 * h;
+        const int t0s = __builtin_amdgcn_readfirstlane(t0);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             if (!any_ge(m4[g4], ct)) continue;
 #pragma unroll
-            for (int r = 4 * g4; r < 4 * g4 + 4; ++r) hit(acc[r], jb + (r & 3) + 8 * (r >> 2), ct);
+            for (int r = 4 * g4; r < 4 * g4 + 4; ++r) hit(acc[r], t0s + (r & 3) + 8 * (r >> 2), ct);
         }
         thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
     };
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
                 const int c = min(cnt[o * slots + slot], kCapH);
                 if (sl + kRL * pass < c) {
                     const int2 e = list[(o * slots + slot) * kCapH + sl + kRL * pass];
-                    if (__int_as_float(e.y) >= bound) j = e.x;
+                    if (__int_as_float(e.y) >= bound) j = e.x + 4 * (slot & 1);     // the segment's lane half: rows +4
                 }
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(j >= 0);
