@@ -85,7 +85,7 @@ def test_hamming_planted_matches_recovered(device):
     assert np.array_equal(idx, ri) and np.array_equal(d1.cpu().numpy()[0], r1) and np.array_equal(d2.cpu().numpy()[0], r2)
 
 
-PRECISIONS = [0, 1]     # f32 MFMA kernel / bf16x3 filter + exact re-rank: same bit-exact contract
+PRECISIONS = [0, 1]     # f32 MFMA kernel / fp16 candidate filter + exact re-rank: same bit-exact contract
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -146,7 +146,7 @@ def test_l2_filter_adversarial_inputs(device):
     reference at these sizes.  (a) train rows sorted by increasing similarity: every row beats the running
     bound, the lists overflow and the exact fallback scan must take over; (b) all train rows identical: every
     row ties; (c) wide dynamic range: row norms from 1e-3 to 1e3, the error band is set by the largest norm;
-    (d) near-duplicates differing in the last bits: ordering decided below the bf16x3 resolution."""
+    (d) near-duplicates differing in the last bits: ordering decided far below the filter's resolution."""
     rng = np.random.default_rng(99)
     q = synthetic.sift_like(rng, 700, 128)
     # (a)
@@ -169,6 +169,39 @@ def test_l2_filter_adversarial_inputs(device):
     ri, r1, r2 = orc.match_l2_top2(q, ta)
     f = matching.match_l2(_t(q[None], device), _t(ta[None], device), precision=1)
     assert np.array_equal(f[0].cpu().numpy()[0], ri)
+
+
+def test_l2_filter_fp16_range_cases(device):
+    """The filter computes in fp16 after a per-pair power-of-two scaling.  Cases aimed at that: (e) row norms spread
+    over 12 decades on both sides — most elements land below fp16's normal range or at zero, the band's absolute term
+    must cover them; (f) integer-valued 0..255 descriptors (OpenCV SIFT convention), norms ~500; (g) one giant row
+    among unit rows (it sets the scale, everything else is tiny); (h) everything scaled by 1e-16: the scales leave
+    the supported range and every query takes the exact path; (i) all-zero train rows / zero queries; (j) large
+    magnitudes (1e15), where unscaled fp16 would overflow."""
+    rng = np.random.default_rng(1234)
+    q = synthetic.sift_like(rng, 300, 128)
+    t = synthetic.sift_like(rng, 2500, 128)
+    cases = []
+    te = (t * np.exp(rng.uniform(np.log(1e-8), np.log(1e4), (2500, 1)))).astype(np.float32)
+    qe = (q * np.exp(rng.uniform(np.log(1e-8), np.log(1e4), (300, 1)))).astype(np.float32)
+    cases.append((qe, te))
+    cases.append((np.floor(q * 512).clip(0, 255).astype(np.float32), np.floor(t * 512).clip(0, 255).astype(np.float32)))
+    tg = t.copy(); tg[1234] *= 3.0e4
+    cases.append((q, tg))
+    cases.append(((q * 1e-16).astype(np.float32), (t * 1e-16).astype(np.float32)))
+    tz = t.copy(); tz[:] = 0.0
+    qz = q.copy(); qz[::3] = 0.0
+    cases.append((q, tz)); cases.append((qz, t))
+    cases.append(((q * 1e15).astype(np.float32), (t * 1e15).astype(np.float32)))
+    for qq, tt in cases:
+        a = matching.match_l2(_t(qq[None], device), _t(tt[None], device), precision=0)
+        f = matching.match_l2(_t(qq[None], device), _t(tt[None], device), precision=1)
+        _assert_same_bits(a, f)
+    # and once against the CPU oracle, on the widest-range case
+    ri, r1, r2 = orc.match_l2_top2(qe, te)
+    f = matching.match_l2(_t(qe[None], device), _t(te[None], device), precision=1)
+    assert np.array_equal(f[0].cpu().numpy()[0], ri)
+    assert np.array_equal(f[1].cpu().numpy()[0].view(np.uint32), r1.view(np.uint32))
 
 
 def test_l2_filter_full_size_equals_f32_kernel(device):
