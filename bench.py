@@ -5,7 +5,7 @@ Workload (BASELINE.json configs[1]): synthetic two-view pairs, 8192 SIFT-style f
 descriptors (dim 128) per view, 4096 RANSAC essential-matrix hypotheses per pair.  One step =
 one pass of the hot path over a batch of --pairs such pairs per GPU, inputs resident in HBM:
 
-    row norms -> L2 top-2 (fp32 MFMA) -> ratio test -> compaction -> Philox minimal samples ->
+    row norms -> L2 top-2 (fp16 MFMA candidate filter + exact f32 re-rank) -> ratio test -> compaction -> Philox minimal samples ->
     5-point solver (hypothesis generation) -> Sampson scoring of H hypotheses -> best -> inlier mask ->
     decomposition of the winning E (closed form on the device; --decompose host = NumPy SVD) -> 4-candidate
     triangulation + cheirality vote -> pose table  (-> all_gather of the table when N > 1)
@@ -28,7 +28,8 @@ sys.path.insert(0, ROOT)
 from pose_estimation_amd import matching, pipeline, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_BF16_MFMA_TFLOPS = 2516.6  # MI355X_MICROARCH.md: ~2.5 PF dense = 1024 SIMDs x 32768 FLOP / 32 cyc x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 1024 SIMDs x 32768 FLOP / 32 cyc x 2.4 GHz
+L2_CALL_HBM_BYTES_AT_32_PAIRS = 848.0e6   # (1.1 + 66.3 + 100.0 + 169.9) MB FETCH_SIZE x 2 + (2.1 + 67.6 + 100.8 + 3.1) MB WRITE_SIZE
 N_FEAT, DIM = 8192, 128
 N_SAMPLES = 410                 # minimal samples per pair; the 5-point solver fills 10 hypothesis slots each
 N_HYP = 10 * N_SAMPLES          # 4100 essential-matrix hypotheses scored per pair (>= the 4096 of configs[1])
@@ -83,7 +84,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed through the CPU oracle (0 = skip)")
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
-                         "1 = bf16x3 MFMA candidate filter + exact f32 re-rank")
+                         "1 = fp16 MFMA candidate filter + exact f32 re-rank")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the batches alternate over: with 2, the latency-bound RANSAC stages of one batch "
                          "run beside the MFMA-bound matcher of the next")
@@ -178,6 +179,18 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     flops = 2.0 * N_FEAT * N_FEAT * DIM * P
     achieved = flops / (kern_ms * 1e-3) / 1e12
+    # the same matcher call alone on the device (no other stream's kernels beside it): 5 launches after the timed region
+    nq_, nt_ = matching.row_sqnorm(batch["desc_q"]), matching.row_sqnorm(batch["desc_t"])
+    iso = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq_, norm_t=nt_, precision=args.precision)
+        b.record()
+        torch.cuda.synchronize()
+        iso.append(a.elapsed_time(b))
+    iso_ms = float(np.mean(iso[1:]))
 
     if args.check and rank == 0:
         from pose_estimation_amd import geometry
@@ -193,17 +206,20 @@ def main():
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                     "traffic": None, "launch_ms": kern_ms, "algorithmic_flops_per_launch": flops}
     else:
-        # One ph_match_l2_top2 call = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel; the events bracket
-        # the call.  `achieved` counts the ALGORITHMIC 2*N*M*D flops per pair; the filter executes 3 bf16 MFMA products
-        # per algorithmic product (+3 % priming), so its ceiling on this scale is a third of the bf16 peak.
+        # One ph_match_l2_top2 call = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel; the
+        # events bracket the call on its own stream.  `achieved` counts the ALGORITHMIC 2*N*M*D flops per pair; the filter
+        # executes one fp16 MFMA product per algorithmic product (+3 % priming).  With --streams > 1 other batches' kernels
+        # share the device during the call, so launch_ms is the duration under that contention; isolated_launch_ms is the
+        # same call alone.
         roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
-                    "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_BF16_MFMA_TFLOPS,
-                    # HBM bytes per launch of 16 pairs, rocprofv3 --pmc offline (profiles/r1/l2_filter_pmc_summary.json):
-                    # FETCH_SIZE x2 (gfx950 correction) 135 MB filter + 185 MB re-rank, WRITE_SIZE 33 MB; scaled by pairs
-                    "traffic": 353.0e6 * P / 16, "launch_ms": kern_ms,
-                    "algorithmic_flops_per_launch": flops, "executed_bf16_mfma_flops_per_launch": flops * 3 * (1 + 8 / 256),
-                    "executed_frac_of_bf16_peak": achieved * 3 * (1 + 8 / 256) / PEAK_BF16_MFMA_TFLOPS,
+                    "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+                    # HBM bytes per launch, rocprofv3 --pmc offline (profiles/r1/l2_filter_f16_pmc_summary.json): FETCH_SIZE x2
+                    # (gfx950 correction) + WRITE_SIZE over the four kernels of the call at 32 pairs; scaled by pairs
+                    "traffic": L2_CALL_HBM_BYTES_AT_32_PAIRS * P / 32, "launch_ms": kern_ms, "isolated_launch_ms": iso_ms,
+                    "isolated_achieved": flops / (iso_ms * 1e-3) / 1e12,
+                    "isolated_frac": flops / (iso_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                    "algorithmic_flops_per_launch": flops, "executed_f16_mfma_flops_per_launch": flops * (1 + 8 / 256),
                     "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                     "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0, 81 % of the f32 MFMA peak)"}
     if rank == 0:

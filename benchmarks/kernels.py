@@ -20,7 +20,7 @@ from pose_estimation_amd import matching, ransac, synthetic, triangulation  # no
 
 VALU_PEAK = 256 * 4 * 32 * 2.4e9
 MFMA_F32_PEAK = 157.3e12
-MFMA_BF16_PEAK = 2516.6e12   # ~2.5 PF dense nominal (2.4 GHz); 1.25-1.5 PF sustained on random data (MI355X_MICROARCH.md)
+MFMA_F16_PEAK = 2516.6e12   # ~2.5 PF dense nominal (2.4 GHz); 1.25-1.5 PF sustained on random data (MI355X_MICROARCH.md)
 MFMA_I8_PEAK = 5033.2e12     # i8 MFMA: 2x the bf16 rate per clock
 HBM_PEAK = 8.0e12
 
@@ -66,9 +66,9 @@ def main():
             report("l2_top2_f32_kernel<128>", f"{P} pair(s) 8192x8192x128 f32", med, best, 2.0 * n * n * d * P, "FLOP/s",
                    MFMA_F32_PEAK, {"bound": "mfma", "hbm_frac": (2 * n * d * 4 + n * 12) * P / med / HBM_PEAK})
             med, best = timeit(lambda: matching.match_l2(tab, tab, vq, vt, norm_q=nrm, norm_t=nrm, precision=1), args.iters)
-            report("l2 filter + re-rank (prep + l2_filter_kernel<4> + l2_rerank_kernel)", f"{P} pair(s) 8192x8192x128 f32",
-                   med, best, 2.0 * n * n * d * P, "FLOP/s", MFMA_BF16_PEAK,
-                   {"bound": "mfma", "note": "algorithmic FLOP over the nominal bf16 peak; 3.09 bf16 MFMA FLOP are executed per "
+            report("l2 filter + re-rank (prep + presplit + l2_filter_kernel<4> + l2_rerank_kernel)", f"{P} pair(s) 8192x8192x128 f32",
+                   med, best, 2.0 * n * n * d * P, "FLOP/s", MFMA_F16_PEAK,
+                   {"bound": "mfma", "note": "algorithmic FLOP over the nominal f16 peak; 1.03 f16 MFMA FLOP are executed per "
                     "algorithmic FLOP", "over_f32_mfma_peak": 2.0 * n * n * d * P / med / MFMA_F32_PEAK})
 
     if not only or "hamming" in only:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Candidate-list statistics of the bf16x3 filter (reads the workspace the C ABI call leaves behind)."""
+"""Candidate-list statistics of the fp16 candidate filter (reads the workspace the C ABI call leaves behind)."""
 import os, sys
 import numpy as np
 import torch
@@ -29,8 +29,8 @@ idx = torch.empty((P, n), dtype=torch.int32, device=dev); d1 = torch.empty((P, n
 L.check(lib.ph_match_l2_top2(L.ptr(tab), L.ptr(tab), L.ptr(nrm), L.ptr(nrm), L.ptr(vq), L.ptr(vt), None, None, P, n, n, 128, prec,
                              L.ptr(idx), L.ptr(d1), L.ptr(d2), L.ptr(ws), wsb, L.stream_ptr()), "l2")
 torch.cuda.synchronize()
-off = (P * 4 + 255) // 256 * 256
-slots = 2 * max(1, -(-512 // (P * (n // 256))))          # plan_l2_filter: two 4-wave blocks per CU
+off = (2 * P * 4 + 255) // 256 * 256
+slots = 2 * min(max(1, -(-512 // (P * (n // 256)))), -(-n // 2048))   # plan_l2_filter: two 4-wave blocks per CU, >= 32 staged tiles per split
 cnt = ws[off:off + P * n * slots * 4].view(torch.int32).cpu().numpy().reshape(P * n, slots)
 print(f"slots {slots}: per-segment max {cnt.max()} (capacity 32), overflowing queries {(cnt.max(1) > 32).mean():.5f}")
 cnt = cnt.sum(1)

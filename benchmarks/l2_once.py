@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Launch the L2 matcher a few times at one shape (for rocprofv3 passes) and print HIP-event times.
 
-    python3 benchmarks/l2_once.py [pairs] [precision]     # precision 0 = f32 MFMA, 1 = bf16x3 filter + re-rank
+    python3 benchmarks/l2_once.py [pairs] [precision]     # precision 0 = f32 MFMA, 1 = fp16 filter + re-rank
 """
 import os, sys
 import torch

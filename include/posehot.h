@@ -77,12 +77,12 @@ int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float* out, void*
  * ([Vq][nq], [Vt][nt]).  precision selects the ALGORITHM, never the result — both give the same
  * bit-exact outputs (the f32 fma-chain contract of DESIGN.md §4):
  *   PH_PRECISION_F32           every score on v_mfma_f32_32x32x2_f32;
- *   PH_PRECISION_BF16X3_RERANK three bf16 MFMA products per score select ~10 candidate rows per query
- *                              inside a proven error band, the contract's f32 chain re-ranks them
- *                              (dim 128; dim 64 runs the f32 kernel).  Needs workspace.
+ *   PH_PRECISION_F16_RERANK    one fp16 MFMA product per score (rows scaled per pair by powers of two) selects
+ *                              ~11 candidate rows per query inside a proven error band, the contract's f32
+ *                              chain re-ranks them (dim 128; dim 64 runs the f32 kernel).  Needs workspace.
  * d1sq/d2sq = squared distances of the best / second-best train row (+inf when absent). */
 #define PH_PRECISION_F32 0
-#define PH_PRECISION_BF16X3_RERANK 1
+#define PH_PRECISION_F16_RERANK 1
 size_t ph_match_l2_ws_bytes(int B, int nq, int nt, int dim, int precision);
 int ph_match_l2_top2(const float* desc_q, const float* desc_t,
                      const float* norm_q, const float* norm_t,

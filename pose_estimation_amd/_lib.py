@@ -18,7 +18,7 @@ PH_OK = 0
 PH_NO_INDEX = -1
 PH_HAMMING_NONE = 0x7FFFFFFF
 PRECISION_F32 = 0
-PRECISION_BF16X3_RERANK = 1
+PRECISION_F16_RERANK = 1
 
 
 class PosehotError(RuntimeError):

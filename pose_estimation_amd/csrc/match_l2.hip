@@ -307,7 +307,7 @@ extern "C" int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float*
 
 extern "C" size_t ph_match_l2_ws_bytes(int B, int nq, int nt, int dim, int precision) {
     if (B <= 0 || nq <= 0 || nt <= 0) return 0;
-    if (precision == PH_PRECISION_BF16X3_RERANK && dim == 128) return plan_l2_filter(B, nq, nt).total;
+    if (precision == PH_PRECISION_F16_RERANK && dim == 128) return plan_l2_filter(B, nq, nt).total;
     return plan_l2(B, nq, nt).total;
 }
 
@@ -320,12 +320,12 @@ extern "C" int ph_match_l2_top2(const float* desc_q, const float* desc_t,
                                 void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
     if (dim != 128 && dim != 64) return PH_ERR_UNSUPPORTED;
-    if (precision != PH_PRECISION_F32 && precision != PH_PRECISION_BF16X3_RERANK) return PH_ERR_UNSUPPORTED;
+    if (precision != PH_PRECISION_F32 && precision != PH_PRECISION_F16_RERANK) return PH_ERR_UNSUPPORTED;
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || nq == 0) return PH_OK;
     if (!desc_q || !norm_q || !idx || !d1sq || !d2sq || (nt > 0 && (!desc_t || !norm_t))) return PH_ERR_INVALID_ARG;
     if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
-    if (precision == PH_PRECISION_BF16X3_RERANK && dim == 128) {       // dim 64 takes the f32 kernel: same outputs
+    if (precision == PH_PRECISION_F16_RERANK && dim == 128) {       // dim 64 takes the f32 kernel: same outputs
         const L2FilterPlan fp = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
         if (!ws || ws_bytes < fp.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
         return launch_l2_filter(desc_q, desc_t, norm_q, norm_t, view_q, view_t, n_q, n_t, B, nq, nt, idx, d1sq, d2sq, ws,

@@ -73,13 +73,13 @@ def row_sqnorm(table):
     return out
 
 
-def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, precision=L.PRECISION_BF16X3_RERANK,
+def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, precision=L.PRECISION_F16_RERANK,
              norm_q=None, norm_t=None):
     """Squared-L2 top-2.  Returns (idx int32, d1sq f32, d2sq f32), each ``[B, nq]``.
 
     precision picks the algorithm, not the result (both follow the f32 fma-chain contract bit for bit):
-    ``L.PRECISION_F32`` scores every pair of rows on the f32 MFMA; ``L.PRECISION_BF16X3_RERANK`` (default) filters
-    candidates with three bf16 MFMA products per score and re-ranks them with the exact chain.
+    ``L.PRECISION_F32`` scores every pair of rows on the f32 MFMA; ``L.PRECISION_F16_RERANK`` (default) filters
+    candidates with one fp16 MFMA product per score (inside a proven error band) and re-ranks them with the exact chain.
 
     norm_q / norm_t: cached ``row_sqnorm`` of the tables (computed here when not given).
     """
