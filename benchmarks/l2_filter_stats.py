@@ -30,7 +30,7 @@ L.check(lib.ph_match_l2_top2(L.ptr(tab), L.ptr(tab), L.ptr(nrm), L.ptr(nrm), L.p
                              L.ptr(idx), L.ptr(d1), L.ptr(d2), L.ptr(ws), wsb, L.stream_ptr()), "l2")
 torch.cuda.synchronize()
 off = (2 * P * 4 + 255) // 256 * 256
-slots = 2 * min(max(1, -(-512 // (P * (n // 256)))), -(-n // 2048))   # plan_l2_filter: two 4-wave blocks per CU, >= 32 staged tiles per split
+slots = 2 * min(max(1, -(-512 // (P * (n // 256)))), -(-n // 1024))   # plan_l2_filter: two 4-wave blocks per CU, >= 16 staged tiles per split
 cnt = ws[off:off + P * n * slots * 4].view(torch.int32).cpu().numpy().reshape(P * n, slots)
 print(f"slots {slots}: per-segment max {cnt.max()} (capacity 32), overflowing queries {(cnt.max(1) > 32).mean():.5f}")
 cnt = cnt.sum(1)

@@ -577,7 +577,7 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
     L2FilterPlan p;
     const long blocks = (long)B * ph_ceil_div(nq, kWaves * 32 * kQT);
     int s = (int)((256 * kBlocksPerCU + blocks - 1) / blocks);   // fill every CU once
-    const int max_s = ph_ceil_div(nt, 32 * kSR);                // at least 32 staged tiles per split
+    const int max_s = ph_ceil_div(nt, 16 * kSR);                // at least 16 staged tiles (1024 rows) per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
