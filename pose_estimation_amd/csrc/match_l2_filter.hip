@@ -45,6 +45,7 @@ constexpr int kCPR = kDim / 8;  // 16-byte fp16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
 constexpr int kCapH = 32;      // list entries per (query, split, lane half)
 constexpr int kBlocksPerCU = 2;
+constexpr int kPrimeRows = 512;   // rows of the priming pass (per split)
 
 // ---- per-pair scales and the error band (one definition for the three kernels) -------------------------------------
 struct PairScale {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     const int t_end = min(ntv, t_begin + rows_per_split);
     if (t_begin >= t_end) return;
     const int n_tiles = (t_end - t_begin + kSR - 1) / kSR;
-    const int n_prime = min(8 / kSub, max(1, n_tiles / 16));
+    const int n_prime = min(kPrimeRows / kSR, max(1, n_tiles / 8));
 
     // staged tile -> LDS buffer: wave w copies KB slices w, w+4, ... and its share of the tail, asynchronously
     auto stage = [&](int tile, int buf) {
@@ -307,7 +308,11 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
 #pragma unroll
             for (int r = 4 * g4; r < 4 * g4 + 4; ++r) hit(acc[r], t0s + (r & 3) + 8 * (r >> 2), ct);
         }
-        thr[ct] = vmax(thr[ct], __shfl_xor(thr[ct], 32));       // the other lane half holds the same query
+        // the other lane half holds the same query (its other rows): the second-largest of the union of the two
+        // halves' top-2 is the tighter bound — half of the time the best two rows sit in different halves
+        const float o1 = __shfl_xor(a1[ct], 32), o2 = __shfl_xor(a2[ct], 32), ot = __shfl_xor(thr[ct], 32);
+        const float second = vmax(fminf(a1[ct], o1), vmax(a2[ct], o2));
+        thr[ct] = vmax(vmax(thr[ct], ot), second - eps2[ct]);
     };
 
     // Staging pipeline: a ring of three LDS buffers, one barrier per staged tile, copies two tiles ahead.  At the top
