@@ -3,10 +3,11 @@
 
     python benchmarks/configs.py --cfg 3            # 100-camera ring, 4,950 pairs, 32k binary descriptors
     python benchmarks/configs.py --cfg 4 --pairs N  # 1,000 views, 8k binary descriptors, first N of 499,500 pairs
+    python benchmarks/configs.py --cfg 4 --f32      # the same with 8k x 128 float32 descriptors (L2 matcher)
     python benchmarks/configs.py --cfg 5            # 32 frames x 65,536 2-D/3-D correspondences, 16,384 P3P hypotheses
 
-Prints one JSON line: pairs/s over the whole pair list (views resident, pairs in chunks, the front of chunk
-k+1 enqueued before the host finishes chunk k) and the accuracy against the synthetic ground truth.
+Prints one JSON line: pairs/s over the whole pair list (views resident, pairs in chunks that alternate over
+--streams HIP streams, no host round trip inside a chunk) and the accuracy against the synthetic ground truth.
 """
 import argparse
 import json
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--samples", type=int, default=410)
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--f32", action="store_true", help="cfg 3/4 with float32 x 128 descriptors and the L2 matcher")
+    ap.add_argument("--streams", type=int, default=3)
     args = ap.parse_args()
     if args.cfg == 5:
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -82,34 +85,43 @@ def main():
     torch.cuda.set_device(dev)
 
     t0 = time.perf_counter()
-    sc = synthetic.binary_views(V, n, seed=1000 + args.cfg, config=args.cfg)
+    if args.f32:
+        sc = synthetic.float_views(V, n, seed=1000 + args.cfg, config=args.cfg)
+    else:
+        sc = synthetic.binary_views(V, n, seed=1000 + args.cfg, config=args.cfg)
     gen_s = time.perf_counter() - t0
+    print(f"# scene generated in {gen_s:.1f} s", file=sys.stderr, flush=True)
     desc = torch.from_numpy(sc["desc"]).to(dev)
     kp = torch.from_numpy(sc["kp"]).to(dev)
+    norms = matching.row_sqnorm(desc) if args.f32 else None
     vi, vj = synthetic.all_pairs(V)
     if args.pairs:
         vi, vj = vi[:args.pairs], vj[:args.pairs]
     mine = sharding.shard_indices(len(vi), rank, world).numpy()         # block-cyclic shard of the pair list
     vi, vj = vi[mine], vj[mine]
     thr_sq = float(np.float32((1.5 / synthetic.FX) ** 2))
+    vi_d, vj_d = torch.from_numpy(vi).to(dev), torch.from_numpy(vj).to(dev)
 
-    def front(s, e):
-        q = torch.from_numpy(vi[s:e]).to(dev); t = torch.from_numpy(vj[s:e]).to(dev)
-        return pipeline.relative_pose_front(lambda: (*matching.match_hamming(desc, desc, q, t), "hamming"), kp, kp, q, t,
-                                            None, thr_sq, ratio=0.8, n_samples=args.samples, seed=s)
+    def chunk(s, e):
+        q, t = vi_d[s:e], vj_d[s:e]
+        if args.f32:
+            match = lambda: (*matching.match_l2(desc, desc, q, t, norm_q=norms, norm_t=norms), "l2")
+        else:
+            match = lambda: (*matching.match_hamming(desc, desc, q, t), "hamming")
+        return pipeline.relative_pose_batch(match, kp, kp, q, t, None, thr_sq, ratio=0.8, n_samples=args.samples,
+                                            seed=s)["table"]
 
-    tables = []
-    f = front(0, min(args.chunk, len(vi)))             # warm-up chunk (also first real chunk's shapes)
-    pipeline.relative_pose_back(f)
+    chunk(0, min(args.chunk, len(vi)))                  # warm-up chunk (also the first real chunk's shapes)
     torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    tables = []
     t0 = time.perf_counter()
-    pending = None
-    for s in range(0, len(vi), args.chunk):
-        f = front(s, min(s + args.chunk, len(vi)))
-        if pending is not None:
-            tables.append(pipeline.relative_pose_back(pending)["table"])
-        pending = f
-    tables.append(pipeline.relative_pose_back(pending)["table"])
+    for k, s in enumerate(range(0, len(vi), args.chunk)):
+        with torch.cuda.stream(streams[k % len(streams)]):
+            tables.append(chunk(s, min(s + args.chunk, len(vi))))
+        if k % 256 == 255:
+            print(f"# {s + args.chunk} pairs enqueued", file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
     table = torch.cat(tables)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -121,7 +133,8 @@ def main():
         rerr.append(geometry.rotation_angle_deg(tab[p, :9].reshape(3, 3), R))
         terr.append(geometry.direction_angle_deg(tab[p, 9:12], t))
     rerr, terr = np.array(rerr), np.array(terr)
-    print(json.dumps({"cfg": args.cfg, "views": V, "features": n, "pairs": int(len(vi)), "rank": rank, "world": world,
+    print(json.dumps({"cfg": args.cfg, "descriptors": "f32x128" if args.f32 else "256-bit", "streams": args.streams,
+                      "views": V, "features": n, "pairs": int(len(vi)), "rank": rank, "world": world,
                       "seconds": dt, "pairs_per_s": len(vi) / dt, "hyps_per_s": len(vi) * 10 * args.samples / dt,
                       "scene_generation_s": gen_s, "median_matches": float(np.median(tab[:, 13])),
                       "median_inliers": float(np.median(tab[:, 12])),

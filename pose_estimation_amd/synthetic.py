@@ -162,6 +162,36 @@ def binary_views(n_views, n_feat, n_landmarks=None, p_flip=0.05, seed=None, conf
     return dict(desc=desc, kp=kp, ids=ids, R=Rs, t=ts)
 
 
+def float_views(n_views, n_feat, n_landmarks=None, sigma_desc=0.05, seed=None, config=4, radius=3.0, dim=128):
+    """SIFT-like float views of one landmark set: the f32 variant of `binary_views` (same cameras, same
+    observation model; a view sees a random subset of the landmarks, each descriptor perturbed by
+    N(0, sigma_desc) and renormalised).  Returns desc float32 [V, n_feat, dim], kp, ids, R, t."""
+    rng = rng_for(config, seed)
+    L = n_landmarks or 2 * n_feat
+    codes = sift_like(rng, L, dim)
+    Xw = rng.uniform(-1.0, 1.0, (L, 3))
+    Rs, ts = [], []
+    per_ring = 100
+    for v0 in range(0, n_views, per_ring):
+        nv = min(per_ring, n_views - v0)
+        Rr, tr = ring_cameras(nv, radius, 0.5 + 0.1 * (v0 // per_ring), (0.0, 0.0, 0.0), phase=0.013 * v0)
+        Rs.append(Rr); ts.append(tr)
+    Rs, ts = np.concatenate(Rs), np.concatenate(ts)
+    desc = np.empty((n_views, n_feat, dim), np.float32)
+    kp = np.empty((n_views, n_feat, 2), np.float32)
+    ids = np.empty((n_views, n_feat), np.int32)
+    for v in range(n_views):
+        sel = rng.permutation(L)[:n_feat]
+        ids[v] = sel
+        d = codes[sel] + rng.standard_normal((n_feat, dim), dtype=np.float32) * np.float32(sigma_desc)
+        np.maximum(d, 0.0, out=d)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        desc[v] = d
+        Xc = Xw[sel] @ Rs[v].T + ts[v]
+        kp[v] = (Xc[:, :2] / Xc[:, 2:3] + rng.normal(0, 1.0 / FX, (n_feat, 2))).astype(np.float32)
+    return dict(desc=desc, kp=kp, ids=ids, R=Rs, t=ts)
+
+
 def all_pairs(n_views):
     i, j = np.triu_indices(n_views, k=1)
     return i.astype(np.int32), j.astype(np.int32)
