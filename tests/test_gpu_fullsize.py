@@ -1,0 +1,113 @@
+"""BASELINE.json's full sizes, checked through properties that do not need the oracle over the whole problem:
+sampled queries / hypotheses against the CPU oracle (which then only sees a thin slice), self-matches,
+split-vs-unsplit agreement, and the sum-of-counts identity of the scoring kernels.  Sizes: cfg 3 (32 768 x 32 768
+binary), cfg 2 (8 192 x 8 192 x 128 f32, 4 096 hypotheses), cfg 5 (65 536 correspondences, 16 384 hypotheses)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from pose_estimation_amd import matching, ransac, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def test_hamming_cfg3_size_sampled_against_oracle(device):
+    sc = synthetic.binary_views(3, 32768, seed=303)
+    d = _t(sc["desc"], device)
+    # three pairs in one launch (no train split) and the first pair alone (train rows split over blocks + merge)
+    vq = _t(np.array([0, 1, 2], np.int32), device); vt = _t(np.array([1, 2, 2], np.int32), device)
+    idx, d1, d2 = (a.cpu().numpy() for a in matching.match_hamming(d, d, vq, vt))
+    one = [a.cpu().numpy() for a in matching.match_hamming(d[:1], d[1:2])]
+    assert np.array_equal(one[0][0], idx[0]) and np.array_equal(one[1][0], d1[0]) and np.array_equal(one[2][0], d2[0])
+    # self-match: every row finds itself at distance 0
+    assert np.array_equal(idx[2], np.arange(32768)) and not d1[2].any()
+    # a thin slice of queries against the oracle (all 32 768 train rows)
+    rng = np.random.default_rng(1)
+    pick = np.sort(rng.choice(32768, 96, replace=False))
+    for b, (q, t) in enumerate(((0, 1), (1, 2), (2, 2))):
+        ri, r1, r2 = orc.match_hamming_top2(sc["desc"][q][pick], sc["desc"][t])
+        assert np.array_equal(idx[b][pick], ri) and np.array_equal(d1[b][pick], r1) and np.array_equal(d2[b][pick], r2)
+    # planted structure: a landmark seen in both views is found through 5 % bit flips
+    common = np.intersect1d(sc["ids"][0], sc["ids"][1])
+    pos_q = {l: i for i, l in enumerate(sc["ids"][0])}; pos_t = {l: i for i, l in enumerate(sc["ids"][1])}
+    hits = sum(idx[0][pos_q[l]] == pos_t[l] for l in common[:2000])
+    assert hits >= 1990
+
+
+def test_l2_cfg2_size_sampled_against_oracle(device):
+    sc = synthetic.two_view_pair(n=8192, seed=2020)
+    q, t = sc["desc1"], sc["desc2"]
+    for precision in (0, 1):
+        idx, d1, d2 = (a.cpu().numpy()[0] for a in matching.match_l2(_t(q[None], device), _t(t[None], device), precision=precision))
+        pick = np.sort(np.random.default_rng(2).choice(8192, 128, replace=False))
+        ri, r1, r2 = orc.match_l2_top2(q[pick], t)
+        assert np.array_equal(idx[pick], ri)
+        assert np.array_equal(d1[pick].view(np.uint32), r1.view(np.uint32))
+        assert np.array_equal(d2[pick].view(np.uint32), r2.view(np.uint32))
+        planted = sc["partner"] >= 0
+        assert (idx[planted] == sc["partner"][planted]).mean() > 0.99
+    # self-match at full size: distance exactly 0 is not guaranteed in f32 (fma(-2, s, |q|^2) with s from a different
+    # chain), the index is
+    idx, d1, _ = matching.match_l2(_t(t[None], device), _t(t[None], device))
+    assert np.array_equal(idx.cpu().numpy()[0], np.arange(8192))
+    assert float(d1.max()) < 1e-5          # unit-norm rows: a few f32 roundings of the two chains
+
+
+def test_score_essential_cfg2_size_equals_oracle(device):
+    """4 100 hypotheses x 8 192 correspondences: the oracle is fast enough for all of them (bit-exact counts)."""
+    sc = synthetic.two_view_pair(n=8192, seed=7)
+    rng = np.random.default_rng(7)
+    x1, y1 = sc["kp1"][:, 0].copy(), sc["kp1"][:, 1].copy()
+    pr = sc["partner"]; ok = pr >= 0
+    x2, y2 = x1.copy(), y1.copy()
+    x2[ok], y2[ok] = sc["kp2"][pr[ok], 0], sc["kp2"][pr[ok], 1]
+    E_true = synthetic.essential_from_pose(sc["R"], sc["t"]); E_true /= np.linalg.norm(E_true)
+    E = rng.standard_normal((4100, 9)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    E[17] = E_true.reshape(9).astype(np.float32)
+    E[100:1500] = 0.0                                   # empty solver slots: skipped on the device, zero by the contract
+    thr = np.float32((1.0 / synthetic.FX) ** 2)
+    cnt = ransac.score_essential(_t(E[None], device), *(_t(a[None], device) for a in (x1, y1, x2, y2)), float(thr)).cpu().numpy()[0]
+    ref = orc.score_essential(E, x1, y1, x2, y2, thr)
+    assert np.array_equal(cnt, ref)
+    assert cnt.argmax() == 17 and cnt[17] > 0.7 * ok.sum() and not cnt[100:1500].any()
+
+
+def test_score_pnp_cfg5_size_sampled_against_oracle(device):
+    """2 frames x 16 384 hypotheses x 65 536 correspondences (point range split over blocks + atomic partial counts):
+    a sample of hypotheses against the oracle, the winner, and the sum-of-counts identity between two launches that
+    split the points differently (B = 2 vs the same frames inside B = 32)."""
+    fr = synthetic.pnp_frames(2, 65536, outliers=0.3, noise_px=1.0, seed=55)
+    rng = np.random.default_rng(55)
+    H = 16384
+    P = np.zeros((2, H, 12), np.float32)
+    for b in range(2):
+        # hypothesis 0 = the truth, 63 perturbed poses, the rest cheap random variations of those (K [R | t + dt])
+        base = synthetic.perturbed_poses(rng, fr["R"][b], fr["t"][b], 64, rot_sigma=0.01, t_sigma=0.02)
+        rep = base[rng.integers(1, 64, H)]
+        rep[:, :, 3] += rng.normal(0, 0.02, (H, 3))
+        rep[0] = base[0]
+        K = np.array([[synthetic.FX, 0, synthetic.CX], [0, synthetic.FY, synthetic.CY], [0, 0, 1.0]])
+        P[b] = (K @ rep).reshape(H, 12).astype(np.float32)
+    P[:, 5000:9000] = 0.0                               # empty P3P slots
+    pts = [fr[k] for k in "XYZuv"]
+    thr = np.float32(8.0 ** 2)
+    cnt = ransac.score_pnp(_t(P, device), *(_t(a, device) for a in pts), float(thr)).cpu().numpy()
+    pick = np.sort(np.concatenate([[0], rng.choice(H, 48, replace=False)]))
+    for b in range(2):
+        ref = orc.score_pnp(P[b][pick], *(a[b] for a in pts), thr)
+        assert np.array_equal(cnt[b][pick], ref)
+        assert cnt[b].argmax() == 0 and not cnt[b, 5000:9000].any()
+        assert abs(int(cnt[b, 0]) - int(fr["inlier_truth"][b].sum())) < 0.02 * 65536
+    # the same two frames as items 30, 31 of a 32-frame launch: other grid shape, same counts
+    P32 = np.zeros((32, H, 12), np.float32); P32[30:] = P
+    big = [np.zeros((32, 65536), np.float32) for _ in pts]
+    for a, s in zip(big, pts):
+        a[:] = s[0]; a[30:] = s
+    cnt32 = ransac.score_pnp(_t(P32, device), *(_t(a, device) for a in big), float(thr)).cpu().numpy()
+    assert np.array_equal(cnt32[30:], cnt) and not cnt32[:30].any()
