@@ -388,13 +388,13 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
 // organised to make them few and wide: (1) the wave's four query rows go to LDS once; (2) every lane reads its list
 // entries of all segments at once and the query's final bound (second-largest listed sA - 2e) is formed by shuffles;
 // (3) the surviving entries of all eight queries (2-3 each) are compacted into a wave queue in LDS; (4) the queued rows
-// are fetched whole, 16 at a time, by all 64 lanes (coalesced 512-byte rows, swizzled into LDS) and lane r runs the
+// are fetched whole, kRC at a time, by all 64 lanes (coalesced 512-byte rows, swizzled into LDS) and lane r runs the
 // exact fma chain of row r out of LDS; (5) lane 0 of each query folds the results into (best, runner-up).
 constexpr int kRL = 8;
 constexpr int kRQ = 64 / kRL;          // queries per wave
-constexpr int kRC = 16;                // rows per fetch chunk
+constexpr int kRC = 8;                 // rows per fetch chunk (16: 224 us, 8: 202 us, 4: 235 us, 32: 477 us — LDS per wave sets the occupancy)
 struct RerankLds {
-    float4 rows[kRC * 32];             // 16 rows x 32 chunks, chunk c of row r at r*32 + (c ^ r)
+    float4 rows[kRC * 32];             // kRC rows x 32 chunks, chunk c of row r at r*32 + (c ^ r)
     float4 qrow[kRQ * 32];
     int qj[64 + kRC];
     int qq[64 + kRC];
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         for (int base = 0; base < n; base += kRC) {
             const int k = min(kRC, n - base);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < kRC / 2; ++i) {
                 const int id = lane + 64 * i, r = id >> 5, c = id & 31;
                 if (r < k) L.rows[r * 32 + (c ^ r)] = Tt[(size_t)L.qj[base + r] * (kDim / 4) + c];
             }
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
                 L.qj[pos] = j; L.qq[pos] = qid;
             }
             n += __builtin_popcountll(m);
-            if (n >= kRC) {                                // keep the queue within its 64 + 16 entries
+            if (n >= kRC) {                                // keep the queue within its 64 + kRC entries
                 wave_sync();
                 const int full = n & ~(kRC - 1);
                 flush(full);
