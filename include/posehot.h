@@ -165,6 +165,22 @@ int ph_score_pnp(const float* P, const float* X, const float* Y, const float* Z,
                  const float* u, const float* v, const int32_t* n_valid,
                  int B, int H, int N, float thr_sq, int32_t* count, void* stream);
 
+/* The same two scorings for callers that only want the winner (RANSAC): a hypothesis is abandoned as soon as its
+ * count so far plus the correspondences not yet seen cannot reach the best count already known for the item.
+ * count[b][h] is then EXACT for every hypothesis that attains the item's maximum and a lower bound (below the
+ * maximum) for the others, so ph_select_best of it returns exactly what it returns for ph_score_*'s exhaustive
+ * counts, ties included.  best_lb is [B] int32 scratch (zeroed by the call; ends as the maximum).  When the launch
+ * splits the correspondences over blocks (few items, many points) the counts are the exhaustive ones.
+ * No reference counterpart (bail-out scoring is the standard RANSAC practice, e.g. Capel 2005). */
+int ph_score_essential_bailout(const float* E, const float* x1, const float* y1,
+                               const float* x2, const float* y2, const int32_t* n_valid,
+                               int B, int H, int N, float thr_sq, int32_t* count, int32_t* best_lb,
+                               void* stream);
+int ph_score_pnp_bailout(const float* P, const float* X, const float* Y, const float* Z,
+                         const float* u, const float* v, const int32_t* n_valid,
+                         int B, int H, int N, float thr_sq, int32_t* count, int32_t* best_lb,
+                         void* stream);
+
 /* argmax over hypotheses, ties -> lowest hypothesis index.  best_idx/best_count are [B]. */
 int ph_select_best(const int32_t* count, int B, int H, int32_t* best_idx, int32_t* best_count,
                    void* stream);

@@ -57,10 +57,16 @@ struct PnpModel {
 
 template <int NA> struct PointArrays { const float* a[NA]; };
 
-template <class Model>
+// Bail = true (only with one point split): a hypothesis is abandoned as soon as its count so far plus the points not
+// yet seen cannot reach the best count known for the item (best_lb[b]: an atomic max every wave feeds with its own
+// running counts, themselves lower bounds of final counts).  An abandoned hypothesis reports the count it had — a lower
+// bound below the maximum — so argmax, ties included, is that of the exhaustive counts; a stale read of best_lb only
+// delays a bail-out.
+template <class Model, bool Bail>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ models, PointArrays<Model::kArrays> pts,
                                                    const int32_t* __restrict__ n_valid, int H, int N, int psplits,
-                                                   int pts_per_split, float thr_sq, int32_t* __restrict__ count) {
+                                                   int pts_per_split, float thr_sq, int32_t* __restrict__ count,
+                                                   int32_t* __restrict__ best_lb) {
     constexpr int NP = Model::kParams, NA = Model::kArrays;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -96,7 +102,20 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
     for (int k = 0; k < kHPW; ++k) cnt[k] = 0;
 
     const size_t row = (size_t)b * N;
+    int known = 0;                                         // best count of the item this wave knows of
     for (int c0 = p_begin; c0 < p_end; c0 += 64 * kPPL) {
+        if (Bail) {
+            const int seen = __hip_atomic_load(best_lb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            known = max(known, __builtin_amdgcn_readfirstlane(seen));
+            const int remaining = p_end - c0;
+            bool any_live = false;
+#pragma unroll
+            for (int k = 0; k < kHPW; ++k) {
+                live[k] = live[k] && (cnt[k] + remaining >= known);
+                any_live |= live[k];
+            }
+            if (!any_live) break;
+        }
         float pt[kPPL][NA];
 #pragma unroll
         for (int p = 0; p < kPPL; ++p) {
@@ -111,6 +130,15 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
             if (!live[k]) continue;
 #pragma unroll
             for (int p = 0; p < kPPL; ++p) cnt[k] += __popcll(__ballot(Model::test(m[k], pt[p], thr_sq)));
+        }
+        if (Bail) {
+            int lb = cnt[0];
+#pragma unroll
+            for (int k = 1; k < kHPW; ++k) lb = max(lb, cnt[k]);
+            if (lb > known) {
+                if (lane == 0) atomicMax(best_lb + b, lb);
+                known = lb;
+            }
         }
     }
     if (lane == 0) {
@@ -197,7 +225,7 @@ ScorePlan plan_score(int B, int H, int N) {
 
 template <class Model>
 int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int32_t* n_valid, int B, int H, int N,
-                 float thr_sq, int32_t* count, void* stream) {
+                 float thr_sq, int32_t* count, int32_t* best_lb, void* stream) {
     if (B < 0 || H < 0 || N < 0) return PH_ERR_INVALID_ARG;
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || H == 0) return PH_OK;
@@ -210,8 +238,15 @@ int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int
         if (N == 0) return PH_OK;
     }
     const dim3 grid(ph_ceil_div(H, 4 * kHPW), p.psplits, B);
-    hipLaunchKernelGGL(score_kernel<Model>, grid, dim3(256), 0, st, models, pts, n_valid, H, N, p.psplits,
-                       p.pts_per_split, thr_sq, count);
+    if (best_lb) {
+        if (hipMemsetAsync(best_lb, 0, sizeof(int32_t) * (size_t)B, st) != hipSuccess) return PH_ERR_LAUNCH;
+    }
+    if (best_lb && p.psplits == 1)
+        hipLaunchKernelGGL((score_kernel<Model, true>), grid, dim3(256), 0, st, models, pts, n_valid, H, N, p.psplits,
+                           p.pts_per_split, thr_sq, count, best_lb);
+    else                      // several point splits add partial counts: no bound to bail out on, exhaustive counts
+        hipLaunchKernelGGL((score_kernel<Model, false>), grid, dim3(256), 0, st, models, pts, n_valid, H, N, p.psplits,
+                           p.pts_per_split, thr_sq, count, best_lb);
     return ph_launch_status();
 }
 
@@ -234,13 +269,27 @@ int mask_launch(const float* models, const int32_t* sel, int H, PointArrays<Mode
 extern "C" int ph_score_essential(const float* E, const float* x1, const float* y1, const float* x2, const float* y2,
                                   const int32_t* n_valid, int B, int H, int N, float thr_sq, int32_t* count,
                                   void* stream) {
-    return score_launch<EssentialModel>(E, PointArrays<4>{{x1, y1, x2, y2}}, n_valid, B, H, N, thr_sq, count, stream);
+    return score_launch<EssentialModel>(E, PointArrays<4>{{x1, y1, x2, y2}}, n_valid, B, H, N, thr_sq, count, nullptr, stream);
+}
+
+extern "C" int ph_score_essential_bailout(const float* E, const float* x1, const float* y1, const float* x2, const float* y2,
+                                          const int32_t* n_valid, int B, int H, int N, float thr_sq, int32_t* count,
+                                          int32_t* best_lb, void* stream) {
+    if (B > 0 && !best_lb) return PH_ERR_INVALID_ARG;
+    return score_launch<EssentialModel>(E, PointArrays<4>{{x1, y1, x2, y2}}, n_valid, B, H, N, thr_sq, count, best_lb, stream);
 }
 
 extern "C" int ph_score_pnp(const float* P, const float* X, const float* Y, const float* Z, const float* u,
                             const float* v, const int32_t* n_valid, int B, int H, int N, float thr_sq, int32_t* count,
                             void* stream) {
-    return score_launch<PnpModel>(P, PointArrays<5>{{X, Y, Z, u, v}}, n_valid, B, H, N, thr_sq, count, stream);
+    return score_launch<PnpModel>(P, PointArrays<5>{{X, Y, Z, u, v}}, n_valid, B, H, N, thr_sq, count, nullptr, stream);
+}
+
+extern "C" int ph_score_pnp_bailout(const float* P, const float* X, const float* Y, const float* Z, const float* u,
+                                    const float* v, const int32_t* n_valid, int B, int H, int N, float thr_sq,
+                                    int32_t* count, int32_t* best_lb, void* stream) {
+    if (B > 0 && !best_lb) return PH_ERR_INVALID_ARG;
+    return score_launch<PnpModel>(P, PointArrays<5>{{X, Y, Z, u, v}}, n_valid, B, H, N, thr_sq, count, best_lb, stream);
 }
 
 extern "C" int ph_select_best(const int32_t* count, int B, int H, int32_t* best_idx, int32_t* best_count, void* stream) {

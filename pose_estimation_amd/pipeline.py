@@ -62,7 +62,7 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     if E_hyp is None:
         samples = ransac.sample_minimal(seed, m["n_match"], pts[0].shape[1], n_samples)
         E_hyp = ransac.solve_essential_5pt(*pts, samples)
-    cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"])
+    cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"], bailout=True)    # only the winner is read
     bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_essential(E_hyp, bi, *pts, thr_sq, m["n_match"])
     if decompose == "device":
@@ -118,7 +118,7 @@ def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096,
 
     X, Y, Z, u, v: float32 ``[B, N]`` SoA rows, (u, v) undistorted pixels; K4 = (fx, fy, cx, cy) float64 device
     tensor.  Returns dict(pose [B,6] f64 (rvec, tvec), pose0 (the winning minimal hypothesis), best_count,
-    best_idx, count [B,H], mask, rms, iters, P_hyp)."""
+    best_idx, count [B,H] (exact for the winner, lower bounds for abandoned hypotheses), mask, rms, iters, P_hyp)."""
     fx, fy, cx, cy = (K4[k].to(torch.float32) for k in range(4))
     xn, yn = (u - cx) / fx, (v - cy) / fy
     B, N = X.shape
@@ -126,7 +126,7 @@ def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096,
     samples = ransac.sample_minimal(seed, n_valid, N, n_samples, m=3) if n_valid is not None else \
         ransac.sample_minimal(seed, torch.full((B,), N, dtype=torch.int32, device=X.device), N, n_samples, m=3)
     P = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4)
-    cnt = ransac.score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid)
+    cnt = ransac.score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid, bailout=True)           # only the winner is read
     bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_pnp(P, bi, X, Y, Z, u, v, thr_sq, n_valid)
     pose0 = ransac.pose_from_projection(P, bi, K4)

@@ -143,8 +143,11 @@ def refine_pose_lm_soa(X, Y, Z, u, v, pose, K4, dist5=None, mask=None, n_valid=N
     return pose, rms, iters
 
 
-def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None):
-    """Inlier count of every E hypothesis (Sampson error < thr).  Returns int32 ``[B, H]``."""
+def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None, bailout=False):
+    """Inlier count of every E hypothesis (Sampson error < thr).  Returns int32 ``[B, H]``.
+
+    bailout=True: hypotheses that can no longer reach the item's best count are abandoned; the counts of the
+    maximum (what ``select_best`` reads) stay exact, the others become lower bounds."""
     lib = L.load()
     x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
     B, N = x1.shape
@@ -152,13 +155,19 @@ def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None):
     H = E.shape[1]
     n_valid = L.opt_i32(n_valid, B, "n_valid")
     count = torch.empty((B, H), dtype=torch.int32, device=E.device)
+    if bailout:
+        lb = torch.empty((B,), dtype=torch.int32, device=E.device)
+        L.check(lib.ph_score_essential_bailout(L.ptr(E), L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(n_valid),
+                                               B, H, N, float(thr_sq), L.ptr(count), L.ptr(lb), L.stream_ptr()),
+                "ph_score_essential_bailout")
+        return count
     L.check(lib.ph_score_essential(L.ptr(E), L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(n_valid),
                                    B, H, N, float(thr_sq), L.ptr(count), L.stream_ptr()), "ph_score_essential")
     return count
 
 
-def score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid=None):
-    """Inlier count of every 3x4 projection hypothesis.  Returns int32 ``[B, H]``."""
+def score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid=None, bailout=False):
+    """Inlier count of every 3x4 projection hypothesis.  Returns int32 ``[B, H]`` (bailout: see ``score_essential``)."""
     lib = L.load()
     X, Y, Z, u, v = _pts((X, Y, Z, u, v), ("X", "Y", "Z", "u", "v"))
     B, N = X.shape
@@ -166,6 +175,12 @@ def score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid=None):
     H = P.shape[1]
     n_valid = L.opt_i32(n_valid, B, "n_valid")
     count = torch.empty((B, H), dtype=torch.int32, device=P.device)
+    if bailout:
+        lb = torch.empty((B,), dtype=torch.int32, device=P.device)
+        L.check(lib.ph_score_pnp_bailout(L.ptr(P), L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(n_valid),
+                                         B, H, N, float(thr_sq), L.ptr(count), L.ptr(lb), L.stream_ptr()),
+                "ph_score_pnp_bailout")
+        return count
     L.check(lib.ph_score_pnp(L.ptr(P), L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(n_valid),
                              B, H, N, float(thr_sq), L.ptr(count), L.stream_ptr()), "ph_score_pnp")
     return count
