@@ -169,9 +169,10 @@ int ph_score_pnp(const float* P, const float* X, const float* Y, const float* Z,
  * count so far plus the correspondences not yet seen cannot reach the best count already known for the item.
  * count[b][h] is then EXACT for every hypothesis that attains the item's maximum and a lower bound (below the
  * maximum) for the others, so ph_select_best of it returns exactly what it returns for ph_score_*'s exhaustive
- * counts, ties included.  best_lb is [B] int32 scratch (zeroed by the call; ends as the maximum).  When the launch
+ * counts, ties included.  best_lb is [B][PH_BAILOUT_SLOTS] int32 scratch (zeroed by the call).  When the launch
  * splits the correspondences over blocks (few items, many points) the counts are the exhaustive ones.
  * No reference counterpart (bail-out scoring is the standard RANSAC practice, e.g. Capel 2005). */
+#define PH_BAILOUT_SLOTS 2048
 int ph_score_essential_bailout(const float* E, const float* x1, const float* y1,
                                const float* x2, const float* y2, const int32_t* n_valid,
                                int B, int H, int N, float thr_sq, int32_t* count, int32_t* best_lb,

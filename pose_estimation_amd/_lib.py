@@ -19,6 +19,7 @@ PH_NO_INDEX = -1
 PH_HAMMING_NONE = 0x7FFFFFFF
 PRECISION_F32 = 0
 PRECISION_F16_RERANK = 1
+BAILOUT_SLOTS = 2048        # int32 words of scratch per item for ph_score_*_bailout (posehot.h)
 
 
 class PosehotError(RuntimeError):

@@ -58,21 +58,24 @@ struct PnpModel {
 template <int NA> struct PointArrays { const float* a[NA]; };
 
 // Bail = true (only with one point split): a hypothesis is abandoned as soon as its count so far plus the points not
-// yet seen cannot reach the best count known for the item (best_lb[b]: an atomic max every wave feeds with its own
-// running counts, themselves lower bounds of final counts).  An abandoned hypothesis reports the count it had — a lower
-// bound below the maximum — so argmax, ties included, is that of the exhaustive counts; a stale read of best_lb only
-// delays a bail-out.
+// yet seen cannot reach the best count known for the item.  That knowledge travels by gossip: the item owns
+// PH_BAILOUT_SLOTS/64 counters, 256 bytes apart (one hot word per item serialises the whole launch in the L2: measured
+// 6x slower than no bail-out at all); every wave walks round them, one per point chunk — the read is issued a chunk
+// ahead — raising the counter to its own best running count (a lower bound of a final count) and taking the larger
+// value along.  An abandoned hypothesis reports the count it had — a lower bound below the maximum — so argmax, ties
+// included, is that of the exhaustive counts; stale knowledge only delays a bail-out.
+constexpr int kRep = PH_BAILOUT_SLOTS / 64, kRepStride = 64;
 template <class Model, bool Bail>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ models, PointArrays<Model::kArrays> pts,
                                                    const int32_t* __restrict__ n_valid, int H, int N, int psplits,
                                                    int pts_per_split, float thr_sq, int32_t* __restrict__ count,
-                                                   int32_t* __restrict__ best_lb) {
+                                                   int32_t* __restrict__ best_lb, int h_begin, int h_end, int tell_all) {
     constexpr int NP = Model::kParams, NA = Model::kArrays;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.z;
-    const int h0 = (blockIdx.x * 4 + wave) * kHPW;
-    if (h0 >= H) return;                                   // wave-uniform; no barriers below
+    const int h0 = h_begin + (blockIdx.x * 4 + wave) * kHPW;
+    if (h0 >= h_end) return;                               // wave-uniform; no barriers below
     const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
     const int p_begin = blockIdx.y * pts_per_split;
     const int p_end = min(nv, p_begin + pts_per_split);
@@ -103,10 +106,17 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
 
     const size_t row = (size_t)b * N;
     int known = 0;                                         // best count of the item this wave knows of
+    int32_t* lbp = Bail ? best_lb + (size_t)b * PH_BAILOUT_SLOTS : nullptr;
+    int rot = (blockIdx.x * 4 + wave) & (kRep - 1);
+    int pending = 0;
+    if (Bail) pending = __hip_atomic_load(lbp + rot * kRepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int c0 = p_begin; c0 < p_end; c0 += 64 * kPPL) {
         if (Bail) {
-            const int seen = __hip_atomic_load(best_lb + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            known = max(known, __builtin_amdgcn_readfirstlane(seen));
+            const int seen = __builtin_amdgcn_readfirstlane(pending);
+            if (known > seen && lane == 0) atomicMax(lbp + rot * kRepStride, known);
+            known = max(known, seen);
+            rot = (rot + 1) & (kRep - 1);
+            pending = __hip_atomic_load(lbp + rot * kRepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int remaining = p_end - c0;
             bool any_live = false;
 #pragma unroll
@@ -135,16 +145,18 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
             int lb = cnt[0];
 #pragma unroll
             for (int k = 1; k < kHPW; ++k) lb = max(lb, cnt[k]);
-            if (lb > known) {
-                if (lane == 0) atomicMax(best_lb + b, lb);
-                known = lb;
-            }
+            known = max(known, lb);
         }
+    }
+    if (Bail && known > 0) {
+        // the seed launch tells every counter what it found (its waves are few); the main launch one more counter
+        if (tell_all) { if (lane < kRep) atomicMax(lbp + lane * kRepStride, known); }
+        else if (lane == 0) atomicMax(lbp + rot * kRepStride, known);
     }
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < kHPW; ++k) {
-            if (h0 + k < H) {
+            if (h0 + k < h_end) {
                 int32_t* dst = count + (size_t)b * H + h0 + k;
                 if (psplits == 1) *dst = cnt[k]; else atomicAdd(dst, cnt[k]);
             }
@@ -239,14 +251,23 @@ int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int
     }
     const dim3 grid(ph_ceil_div(H, 4 * kHPW), p.psplits, B);
     if (best_lb) {
-        if (hipMemsetAsync(best_lb, 0, sizeof(int32_t) * (size_t)B, st) != hipSuccess) return PH_ERR_LAUNCH;
+        if (hipMemsetAsync(best_lb, 0, sizeof(int32_t) * (size_t)B * PH_BAILOUT_SLOTS, st) != hipSuccess) return PH_ERR_LAUNCH;
     }
-    if (best_lb && p.psplits == 1)
-        hipLaunchKernelGGL((score_kernel<Model, true>), grid, dim3(256), 0, st, models, pts, n_valid, H, N, p.psplits,
-                           p.pts_per_split, thr_sq, count, best_lb);
-    else                      // several point splits add partial counts: no bound to bail out on, exhaustive counts
+    if (best_lb && p.psplits == 1) {
+        // Seed launch: the first sixteenth of the hypotheses is scored first (with bail-out among themselves) and leaves
+        // its best count in every counter, so the main launch knows a real final count from its first chunk on — all
+        // waves of one launch start together, and running counts alone let a hopeless hypothesis go only past half
+        // of its points.
+        int h_seed = 0;
+        if (H >= 1024) h_seed = ph_ceil_div(H / 16, 4 * kHPW) * (4 * kHPW);
+        if (h_seed > 0)
+            hipLaunchKernelGGL((score_kernel<Model, true>), dim3(h_seed / (4 * kHPW), 1, B), dim3(256), 0, st, models, pts,
+                               n_valid, H, N, 1, p.pts_per_split, thr_sq, count, best_lb, 0, h_seed, 1);
+        hipLaunchKernelGGL((score_kernel<Model, true>), dim3(ph_ceil_div(H - h_seed, 4 * kHPW), 1, B), dim3(256), 0, st, models,
+                           pts, n_valid, H, N, 1, p.pts_per_split, thr_sq, count, best_lb, h_seed, H, 0);
+    } else                    // several point splits add partial counts: no bound to bail out on, exhaustive counts
         hipLaunchKernelGGL((score_kernel<Model, false>), grid, dim3(256), 0, st, models, pts, n_valid, H, N, p.psplits,
-                           p.pts_per_split, thr_sq, count, best_lb);
+                           p.pts_per_split, thr_sq, count, best_lb, 0, H, 0);
     return ph_launch_status();
 }
 

@@ -156,7 +156,7 @@ def score_essential(E, x1, y1, x2, y2, thr_sq, n_valid=None, bailout=False):
     n_valid = L.opt_i32(n_valid, B, "n_valid")
     count = torch.empty((B, H), dtype=torch.int32, device=E.device)
     if bailout:
-        lb = torch.empty((B,), dtype=torch.int32, device=E.device)
+        lb = torch.empty((B, L.BAILOUT_SLOTS), dtype=torch.int32, device=E.device)
         L.check(lib.ph_score_essential_bailout(L.ptr(E), L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(n_valid),
                                                B, H, N, float(thr_sq), L.ptr(count), L.ptr(lb), L.stream_ptr()),
                 "ph_score_essential_bailout")
@@ -176,7 +176,7 @@ def score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid=None, bailout=False):
     n_valid = L.opt_i32(n_valid, B, "n_valid")
     count = torch.empty((B, H), dtype=torch.int32, device=P.device)
     if bailout:
-        lb = torch.empty((B,), dtype=torch.int32, device=P.device)
+        lb = torch.empty((B, L.BAILOUT_SLOTS), dtype=torch.int32, device=P.device)
         L.check(lib.ph_score_pnp_bailout(L.ptr(P), L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(n_valid),
                                          B, H, N, float(thr_sq), L.ptr(count), L.ptr(lb), L.stream_ptr()),
                 "ph_score_pnp_bailout")
