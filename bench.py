@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU")
-    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs timed through the CPU oracle (0 = skip)")
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
                          "1 = fp16 MFMA candidate filter + exact f32 re-rank")
