@@ -323,11 +323,10 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     // previous iteration are older than those copies) — and only then appends candidates, so no wait ever sees a
     // young store.
     constexpr int kGlds = kImgRows / 256 + 1;        // LDS-DMA instructions per wave per staged tile
-    static_assert(kGlds == 5, "the counted waits below are written for 5");
     const int n_iter = n_prime + n_tiles;
     auto tile_of = [&](int it) { return t_begin / kSR + (it < n_prime ? it : it - n_prime); };
     stage(tile_of(0), 0);
-    if (n_iter > 1) { stage(tile_of(1), 1); asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+    if (n_iter > 1) { stage(tile_of(1), 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int cur = 0, nxt2 = 2;
     for (int it = 0; it < n_iter; ++it) {
@@ -339,7 +338,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         if (more) stage(tile_of(it + 2), nxt2);
         f32x16 acc[kSub][kQT];
         tile_scores(cur, acc);
-        if (more) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int sub = 0; sub < kSub; ++sub) {
