@@ -263,6 +263,157 @@ __global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
     }
 }
 
+// ---- the same matcher on the block-scaled fp4 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands, scales 1.0):
+// twice the K per instruction at the cycles of the int8 form, so half the matrix instructions and half the LDS bytes.
+// A bit becomes a 4-bit float: 1.0 (0x2) in train rows, 2.0 (0x4) in query rows; products and the f32 accumulation of
+// at most 256 of them on top of -|t| are exact, so S = 2 q.t - |t| is the same integer the int8 kernel computes.  The
+// order of K inside a lane does not matter as long as both operands are expanded by the same function (they are).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float kNoScoreF = -1.0e9f;              // exactly representable; padded rows are all-zero, so they keep it
+
+// 8 bits -> 8 nibbles, bit i at bit 4i
+__device__ __forceinline__ uint32_t spread8(uint32_t x) {
+    uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    return (t | (t << 3)) & 0x11111111u;
+}
+// 32 bits -> 32 e2m1 values: bit set -> 1.0 (sh = 1) or 2.0 (sh = 2), clear -> 0
+__device__ __forceinline__ uint4 expand32_fp4(uint32_t w, int sh) {
+    return make_uint4(spread8(w & 0xFFu) << sh, spread8((w >> 8) & 0xFFu) << sh, spread8((w >> 16) & 0xFFu) << sh,
+                      spread8(w >> 24) << sh);
+}
+
+template <int QT>
+__global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(
+    const uint4* __restrict__ dq, const uint32_t* __restrict__ dt,
+    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
+    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
+    int nq, int nt, int splits, int rows_per_split,
+    int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
+    uint2* __restrict__ partial) {
+    __shared__ uint4 tile[2][kMR * 8];            // 32 rows x 256 nibbles, 16-byte chunk c of row r at c ^ (r & 7)
+    __shared__ float4 tneg[2][kMR / 4];           // -|t| per row (the C operand); padded rows: kNoScoreF
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, split = blockIdx.y;
+    const int vq = view_q ? view_q[b] : b;
+    const int vt = view_t ? view_t[b] : b;
+    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const uint4* Q = dq + (size_t)vq * nq * 2;
+    const uint32_t* T = dt + (size_t)vt * nt * 8;
+    const int qw0 = (blockIdx.x * 4 + wave) * (32 * QT);
+
+    // B fragments: k-step s of lane half h covers descriptor dword 2s + h
+    uint4 bq[QT][4];
+    int pq[QT], bi[QT];
+    float m1[QT], m2[QT], bound[QT];
+#pragma unroll
+    for (int ct = 0; ct < QT; ++ct) {
+        const int qi = qw0 + ct * 32 + li;
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (qi < nqv) { a = Q[(size_t)qi * 2]; c = Q[(size_t)qi * 2 + 1]; }
+        const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+        pq[ct] = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pq[ct] += __popc(w[s]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bq[ct][s] = expand32_fp4(h ? w[2 * s + 1] : w[2 * s], 2);
+        m1[ct] = kNoScoreF; m2[ct] = kNoScoreF; bound[ct] = kNoScoreF; bi[ct] = PH_NO_INDEX;
+    }
+
+    const int t_begin = split * rows_per_split;
+    const int t_end = min(ntv, t_begin + rows_per_split);
+
+    // thread tid stages dword (tid & 7) of tile row (tid >> 3): 32 bits -> one 16-byte chunk
+    const int srow = tid >> 3, spart = tid & 7;
+    auto fetch = [&](int t0) -> uint32_t { return (t0 + srow < t_end) ? T[(size_t)(t0 + srow) * 8 + spart] : 0u; };
+    auto commit = [&](int buf, uint32_t wd, int t0) {
+        tile[buf][srow * 8 + (spart ^ (srow & 7))] = expand32_fp4(wd, 1);
+        int pc = __popc(wd);
+        pc += __shfl_xor(pc, 1); pc += __shfl_xor(pc, 2); pc += __shfl_xor(pc, 4);
+        if (spart == 0) ((float*)tneg[buf])[srow] = (t0 + srow < t_end) ? -(float)pc : kNoScoreF;
+    };
+    auto scan = [&](const f32x16& acc, int ct, int t0) {
+        float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
+        mx = fmaxf(mx, acc[15]);
+        if (__builtin_amdgcn_ballot_w64(mx > bound[ct]) == 0ull) return;
+        const int jb = t0 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {           // increasing row index: strict '>' keeps the lowest index
+            const float v = acc[r];
+            const bool gt = v > m1[ct];
+            m2[ct] = fmaxf(fminf(m1[ct], v), m2[ct]);        // second-largest of {m1, m2, v} given m1 >= m2
+            m1[ct] = gt ? v : m1[ct];
+            bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
+        }
+        // The other lane half scans the other rows of the same query.  A row can only enter the query's top-2 (ties:
+        // lowest index for the best, distance only for the runner-up) if it beats the second-largest score of BOTH
+        // halves' top-2 together, all from earlier rows — the tighter entry test, refreshed after every scan.
+        const float o1 = __shfl_xor(m1[ct], 32), o2 = __shfl_xor(m2[ct], 32);
+        bound[ct] = fmaxf(fminf(m1[ct], o1), fmaxf(m2[ct], o2));
+    };
+
+    if (t_begin < t_end) {
+        uint32_t stage = fetch(t_begin);
+        int cur = 0;
+        for (int t0 = t_begin; t0 < t_end; t0 += kMR) {
+            commit(cur, stage, t0);
+            __syncthreads();                       // tile[cur] visible; tile[cur^1] free again
+            if (t0 + kMR < t_end) stage = fetch(t0 + kMR);
+            f32x16 acc[QT];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 z = tneg[cur][2 * g + h];   // rows 8g + 4h .. +3
+                acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
+            }
+#pragma unroll
+            for (int ct = 1; ct < QT; ++ct) acc[ct] = acc[0];
+            const uint4* trow = &tile[cur][li * 8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint4 a4 = trow[(2 * s + h) ^ (li & 7)];
+                const i32x8 a = {(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
+#pragma unroll
+                for (int ct = 0; ct < QT; ++ct) {
+                    const i32x8 bb = {(int)bq[ct][s].x, (int)bq[ct][s].y, (int)bq[ct][s].z, (int)bq[ct][s].w, 0, 0, 0, 0};
+                    acc[ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc[ct], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < QT; ++ct) scan(acc[ct], ct, t0);
+            cur ^= 1;
+        }
+    }
+
+    // merge the two lane halves (same query, disjoint train rows), then emit distances d = |q| - S
+#pragma unroll
+    for (int ct = 0; ct < QT; ++ct) {
+        const float om1 = __shfl_xor(m1[ct], 32), om2 = __shfl_xor(m2[ct], 32);
+        const int obi = __shfl_xor(bi[ct], 32);
+        const bool other = (om1 > m1[ct]) || (om1 == m1[ct] && obi >= 0 && (bi[ct] < 0 || obi < bi[ct]));
+        const float lost = other ? m1[ct] : om1;
+        const float nm2 = fmaxf(lost, fmaxf(m2[ct], om2));
+        const float nm1 = other ? om1 : m1[ct];
+        const int nbi = other ? obi : bi[ct];
+        const int qi = qw0 + ct * 32 + li;
+        if (h != 0 || qi >= nq) continue;
+        uint32_t k1 = kNoKey, k2 = kNoKey;
+        if (qi < nqv && nbi >= 0) {
+            k1 = ((uint32_t)(pq[ct] - (int)nm1) << kIdxBits) + (uint32_t)nbi;
+            if (nm2 != kNoScoreF) k2 = ((uint32_t)(pq[ct] - (int)nm2) << kIdxBits) + kIdxMask;   // runner-up: distance only
+        }
+        if (splits == 1) emit(k1, k2, idx, d1, d2, (size_t)b * nq + qi);
+        else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(k1, k2);
+    }
+}
+
+constexpr bool kHammingFp4 = true;
+
 struct HammingMfmaPlan { int qt, splits, rows_per_split; };
 HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
     HammingMfmaPlan p;
@@ -354,9 +505,10 @@ extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_
     const uint4* q4 = (const uint4*)desc_q;
     const uint32_t* t1 = (const uint32_t*)desc_t;
     uint2* part = (uint2*)ws;
-#define PH_LAUNCH(QT) hipLaunchKernelGGL(hamming_mfma_kernel<QT>, grid, dim3(256), 0, st, q4, t1, view_q, view_t, n_q, \
-                                         n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
-    if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
+#define PH_LAUNCH(K, QT) hipLaunchKernelGGL(K<QT>, grid, dim3(256), 0, st, q4, t1, view_q, view_t, n_q, \
+                                            n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
+    if (kHammingFp4) { if (p.qt == 2) PH_LAUNCH(hamming_fp4_kernel, 2); else PH_LAUNCH(hamming_fp4_kernel, 1); }
+    else { if (p.qt == 2) PH_LAUNCH(hamming_mfma_kernel, 2); else PH_LAUNCH(hamming_mfma_kernel, 1); }
 #undef PH_LAUNCH
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;
