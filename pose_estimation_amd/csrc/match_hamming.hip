@@ -284,29 +284,67 @@ __device__ __forceinline__ uint4 expand32_fp4(uint32_t w, int sh) {
                       spread8(w >> 24) << sh);
 }
 
+// ---- fp4 matcher with the train view expanded ONCE per pair (not once per query block: 128 blocks of a 32 768-row
+// view used to repeat the 32-bit -> 32-nibble expansion of every tile) into ready-made LDS tile images that the query
+// blocks stream with LDS-DMA: no staging registers, VALU or LDS writes in the loop (the scheme of match_l2_filter.hip).
+//   image of a staged tile (64 rows): uint4 [sub*256 + r*8 + (c ^ (r & 7))], sub = 0..1, r = 0..31, c = 16-byte chunk
+//                                     then 64 floats: -|t| per row (kNoScoreF at or beyond the pair's valid count)
+constexpr int kHSub = 2;
+constexpr int kHSR = kMR * kHSub;                       // rows per staged tile
+constexpr int kHImgRows = kHSub * kMR * 8;               // uint4
+constexpr int kHImgTail = kHSR / 4;                      // uint4
+constexpr int kHImg = kHImgRows + kHImgTail;
+__global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __restrict__ dt, const int32_t* __restrict__ view_t,
+                                                            const int32_t* __restrict__ n_t, int nt, int tiles,
+                                                            uint4* __restrict__ img) {
+    const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
+    const int vt = view_t ? view_t[b] : b;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const uint32_t* T = dt + (size_t)vt * nt * 8;
+    uint4* out = img + (size_t)blockIdx.x * kHImg;
+    const int t0 = tile * kHSR;
+#pragma unroll
+    for (int u = 0; u < kHSR * 8 / 256; ++u) {
+        const int id = tid + 256 * u, row = id >> 3, part = id & 7, sub = row >> 5, r = row & 31;
+        const bool ok = t0 + row < ntv;
+        const uint32_t wd = ok ? T[(size_t)(t0 + row) * 8 + part] : 0u;
+        out[sub * (kMR * 8) + r * 8 + (part ^ (r & 7))] = expand32_fp4(wd, 1);
+        int pc = __popc(wd);
+        pc += __shfl_xor(pc, 1); pc += __shfl_xor(pc, 2); pc += __shfl_xor(pc, 4);
+        if (part == 0) ((float*)(out + kHImgRows))[row] = ok ? -(float)pc : kNoScoreF;
+    }
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {      // see match_l2_filter.hip
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <int QT>
-__global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(
-    const uint4* __restrict__ dq, const uint32_t* __restrict__ dt,
-    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
-    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
+__global__ __launch_bounds__(256, 2) void hamming_fp4_dma_kernel(
+    const uint4* __restrict__ dq, const uint4* __restrict__ img, int tiles,
+    const int32_t* __restrict__ view_q, const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int splits, int rows_per_split,
     int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
     uint2* __restrict__ partial) {
-    __shared__ uint4 tile[2][kMR * 8];            // 32 rows x 256 nibbles, 16-byte chunk c of row r at c ^ (r & 7)
-    __shared__ float4 tneg[2][kMR / 4];           // -|t| per row (the C operand); padded rows: kNoScoreF
+    __shared__ uint4 smem[3 * kHImg];             // ring of three staged tiles (ONE LDS object beside the DMA target)
+    static_assert(kHImgRows % 256 == 0 && kHImgTail % 4 == 0, "staging deal");
+    constexpr int kGlds = kHImgRows / 256 + 1;    // LDS-DMA instructions per wave per staged tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int b = blockIdx.z, split = blockIdx.y;
     const int vq = view_q ? view_q[b] : b;
-    const int vt = view_t ? view_t[b] : b;
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
     const uint4* Q = dq + (size_t)vq * nq * 2;
-    const uint32_t* T = dt + (size_t)vt * nt * 8;
+    const uint4* IMG = img + (size_t)b * tiles * kHImg;
     const int qw0 = (blockIdx.x * 4 + wave) * (32 * QT);
 
-    // B fragments: k-step s of lane half h covers descriptor dword 2s + h
     uint4 bq[QT][4];
     int pq[QT], bi[QT];
     float m1[QT], m2[QT], bound[QT];
@@ -324,18 +362,9 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(
         m1[ct] = kNoScoreF; m2[ct] = kNoScoreF; bound[ct] = kNoScoreF; bi[ct] = PH_NO_INDEX;
     }
 
-    const int t_begin = split * rows_per_split;
+    const int t_begin = split * rows_per_split;          // a multiple of kHSR
     const int t_end = min(ntv, t_begin + rows_per_split);
 
-    // thread tid stages dword (tid & 7) of tile row (tid >> 3): 32 bits -> one 16-byte chunk
-    const int srow = tid >> 3, spart = tid & 7;
-    auto fetch = [&](int t0) -> uint32_t { return (t0 + srow < t_end) ? T[(size_t)(t0 + srow) * 8 + spart] : 0u; };
-    auto commit = [&](int buf, uint32_t wd, int t0) {
-        tile[buf][srow * 8 + (spart ^ (srow & 7))] = expand32_fp4(wd, 1);
-        int pc = __popc(wd);
-        pc += __shfl_xor(pc, 1); pc += __shfl_xor(pc, 2); pc += __shfl_xor(pc, 4);
-        if (spart == 0) ((float*)tneg[buf])[srow] = (t0 + srow < t_end) ? -(float)pc : kNoScoreF;
-    };
     auto scan = [&](const f32x16& acc, int ct, int t0) {
         float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
 #pragma unroll
@@ -347,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(
         for (int r = 0; r < 16; ++r) {           // increasing row index: strict '>' keeps the lowest index
             const float v = acc[r];
             const bool gt = v > m1[ct];
-            m2[ct] = fmaxf(fminf(m1[ct], v), m2[ct]);        // second-largest of {m1, m2, v} given m1 >= m2
+            m2[ct] = fmaxf(fminf(m1[ct], v), m2[ct]);
             m1[ct] = gt ? v : m1[ct];
             bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
         }
@@ -359,38 +388,59 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(
     };
 
     if (t_begin < t_end) {
-        uint32_t stage = fetch(t_begin);
-        int cur = 0;
-        for (int t0 = t_begin; t0 < t_end; t0 += kMR) {
-            commit(cur, stage, t0);
-            __syncthreads();                       // tile[cur] visible; tile[cur^1] free again
-            if (t0 + kMR < t_end) stage = fetch(t0 + kMR);
-            f32x16 acc[QT];
+        const int n_iter = (t_end - t_begin + kHSR - 1) / kHSR;
+        const int tile0 = t_begin / kHSR;
+        auto stage = [&](int it, int buf) {
+            const uint4* src = IMG + (size_t)(tile0 + it) * kHImg;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kHImg + wave * 64));
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 z = tneg[cur][2 * g + h];   // rows 8g + 4h .. +3
-                acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
-            }
+            for (int u = 0; u < kHImgRows / 256; ++u) glds16(src + (wave + 4 * u) * 64 + lane, dst + 4096u * u);
+            const unsigned dst_tail = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kHImg + kHImgRows + wave * (kHImgTail / 4)));
+            if (lane < kHImgTail / 4) glds16(src + kHImgRows + wave * (kHImgTail / 4) + lane, dst_tail);
+        };
+        stage(0, 0);
+        if (n_iter > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int cur = 0, nxt2 = 2;
+        for (int it = 0; it < n_iter; ++it) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool more = it + 2 < n_iter;
+            if (more) stage(it + 2, nxt2);
+            f32x16 acc[kHSub][QT];
 #pragma unroll
-            for (int ct = 1; ct < QT; ++ct) acc[ct] = acc[0];
-            const uint4* trow = &tile[cur][li * 8];
+            for (int sub = 0; sub < kHSub; ++sub) {
+                const float4* tneg = (const float4*)(smem + cur * kHImg + kHImgRows) + sub * (kMR / 4);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const uint4 a4 = trow[(2 * s + h) ^ (li & 7)];
-                const i32x8 a = {(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
+                for (int g = 0; g < 4; ++g) {
+                    const float4 z = tneg[2 * g + h];     // rows 8g + 4h .. +3
+                    acc[sub][0][4 * g + 0] = z.x; acc[sub][0][4 * g + 1] = z.y; acc[sub][0][4 * g + 2] = z.z; acc[sub][0][4 * g + 3] = z.w;
+                }
 #pragma unroll
-                for (int ct = 0; ct < QT; ++ct) {
-                    const i32x8 bb = {(int)bq[ct][s].x, (int)bq[ct][s].y, (int)bq[ct][s].z, (int)bq[ct][s].w, 0, 0, 0, 0};
-                    acc[ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc[ct], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                for (int ct = 1; ct < QT; ++ct) acc[sub][ct] = acc[sub][0];
+                const uint4* trow = smem + cur * kHImg + sub * (kMR * 8) + li * 8;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const uint4 a4 = trow[(2 * s + h) ^ (li & 7)];
+                    const i32x8 a = {(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
+#pragma unroll
+                    for (int ct = 0; ct < QT; ++ct) {
+                        const i32x8 bb = {(int)bq[ct][s].x, (int)bq[ct][s].y, (int)bq[ct][s].z, (int)bq[ct][s].w, 0, 0, 0, 0};
+                        acc[sub][ct] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc[sub][ct], 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                    }
                 }
             }
+            if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int ct = 0; ct < QT; ++ct) scan(acc[ct], ct, t0);
-            cur ^= 1;
+            for (int sub = 0; sub < kHSub; ++sub)
+#pragma unroll
+                for (int ct = 0; ct < QT; ++ct) scan(acc[sub][ct], ct, t_begin + it * kHSR + sub * kMR);
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
         }
     }
 
-    // merge the two lane halves (same query, disjoint train rows), then emit distances d = |q| - S
 #pragma unroll
     for (int ct = 0; ct < QT; ++ct) {
         const float om1 = __shfl_xor(m1[ct], 32), om2 = __shfl_xor(m2[ct], 32);
@@ -405,16 +455,15 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_kernel(
         uint32_t k1 = kNoKey, k2 = kNoKey;
         if (qi < nqv && nbi >= 0) {
             k1 = ((uint32_t)(pq[ct] - (int)nm1) << kIdxBits) + (uint32_t)nbi;
-            if (nm2 != kNoScoreF) k2 = ((uint32_t)(pq[ct] - (int)nm2) << kIdxBits) + kIdxMask;   // runner-up: distance only
+            if (nm2 != kNoScoreF) k2 = ((uint32_t)(pq[ct] - (int)nm2) << kIdxBits) + kIdxMask;
         }
         if (splits == 1) emit(k1, k2, idx, d1, d2, (size_t)b * nq + qi);
         else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(k1, k2);
     }
 }
 
-constexpr bool kHammingFp4 = true;
 
-struct HammingMfmaPlan { int qt, splits, rows_per_split; };
+struct HammingMfmaPlan { int qt, splits, rows_per_split, tiles; size_t off_img, total; };
 HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
     HammingMfmaPlan p;
     const long target = 512;                                   // two 4-wave blocks per CU
@@ -426,10 +475,13 @@ HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
-    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kMR) * kMR;
-    if (p.rows_per_split < kMR) p.rows_per_split = kMR;
+    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kHSR) * kHSR;
+    if (p.rows_per_split < kHSR) p.rows_per_split = kHSR;
     p.splits = ph_ceil_div(nt, p.rows_per_split);
     if (p.splits < 1) p.splits = 1;
+    p.tiles = ph_ceil_div(nt, kHSR);
+    p.off_img = p.splits > 1 ? (sizeof(uint2) * (size_t)B * p.splits * nq + 255) / 256 * 256 : 0;
+    p.total = p.off_img + sizeof(uint4) * (size_t)B * p.tiles * kHImg;
     return p;
 }
 
@@ -480,8 +532,7 @@ HammingPlan plan_hamming(int B, int nq, int nt) {
 
 extern "C" size_t ph_match_hamming_ws_bytes(int B, int nq, int nt) {
     if (B <= 0 || nq <= 0 || nt <= 0) return 0;
-    const HammingMfmaPlan p = plan_hamming_mfma(B, nq, nt);
-    return p.splits > 1 ? sizeof(uint2) * (size_t)B * p.splits * nq : 0;
+    return plan_hamming_mfma(B, nq, nt).total;
 }
 
 extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_t,
@@ -497,19 +548,26 @@ extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_
     if (!desc_q || !idx || !d1 || !d2 || (nt > 0 && !desc_t)) return PH_ERR_INVALID_ARG;
     if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const HammingMfmaPlan p = (nt > 0) ? plan_hamming_mfma(B, nq, nt) : HammingMfmaPlan{1, 1, kMR};
-    if (p.splits > 1) {
-        if (!ws || ws_bytes < ph_match_hamming_ws_bytes(B, nq, nt) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
+    const HammingMfmaPlan p = (nt > 0) ? plan_hamming_mfma(B, nq, nt) : HammingMfmaPlan{1, 1, kHSR, 0, 0, 0};
+    if (p.total > 0) {
+        if (!ws || ws_bytes < p.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
     }
     const dim3 grid(ph_ceil_div(nq, 128 * p.qt), p.splits, B);
     const uint4* q4 = (const uint4*)desc_q;
     const uint32_t* t1 = (const uint32_t*)desc_t;
     uint2* part = (uint2*)ws;
-#define PH_LAUNCH(K, QT) hipLaunchKernelGGL(K<QT>, grid, dim3(256), 0, st, q4, t1, view_q, view_t, n_q, \
-                                            n_t, nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
-    if (kHammingFp4) { if (p.qt == 2) PH_LAUNCH(hamming_fp4_kernel, 2); else PH_LAUNCH(hamming_fp4_kernel, 1); }
-    else { if (p.qt == 2) PH_LAUNCH(hamming_mfma_kernel, 2); else PH_LAUNCH(hamming_mfma_kernel, 1); }
+    if (nt > 0) {
+        uint4* img = (uint4*)((char*)ws + p.off_img);
+        hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, t1, view_t, n_t, nt,
+                           p.tiles, img);
+#define PH_LAUNCH(QT) hipLaunchKernelGGL(hamming_fp4_dma_kernel<QT>, grid, dim3(256), 0, st, q4, img, p.tiles, view_q, n_q, n_t, \
+                                         nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
+        if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
 #undef PH_LAUNCH
+    } else {                                   // no train rows: every query gets "no neighbour"
+        hipLaunchKernelGGL(hamming_fp4_dma_kernel<1>, grid, dim3(256), 0, st, q4, (const uint4*)nullptr, 0, view_q, n_q, n_t, nq,
+                           nt, p.splits, p.rows_per_split, idx, d1, d2, part);
+    }
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;
         hipLaunchKernelGGL(hamming_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, B, nq,
