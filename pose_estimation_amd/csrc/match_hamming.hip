@@ -366,19 +366,23 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_dma_kernel(
     const int t_end = min(ntv, t_begin + rows_per_split);
 
     auto scan = [&](const f32x16& acc, int ct, int t0) {
-        float mx = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+        float m4[4];
 #pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, acc[r]), acc[r + 1]);
-        mx = fmaxf(mx, acc[15]);
-        if (__builtin_amdgcn_ballot_w64(mx > bound[ct]) == 0ull) return;
+        for (int g = 0; g < 4; ++g) m4[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
+        const float bnd = bound[ct];
+        if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])) > bnd) == 0ull) return;
         const int jb = t0 + 4 * h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {           // increasing row index: strict '>' keeps the lowest index
-            const float v = acc[r];
-            const bool gt = v > m1[ct];
-            m2[ct] = fmaxf(fminf(m1[ct], v), m2[ct]);
-            m1[ct] = gt ? v : m1[ct];
-            bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
+        for (int g = 0; g < 4; ++g) {            // groups and registers in increasing row order: strict '>' keeps the lowest index
+            if (__builtin_amdgcn_ballot_w64(m4[g] > bnd) == 0ull) continue;     // nobody's top-2 changes in this group
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                const float v = acc[r];
+                const bool gt = v > m1[ct];
+                m2[ct] = fmaxf(fminf(m1[ct], v), m2[ct]);
+                m1[ct] = gt ? v : m1[ct];
+                bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
+            }
         }
         // The other lane half scans the other rows of the same query.  A row can only enter the query's top-2 (ties:
         // lowest index for the best, distance only for the runner-up) if it beats the second-largest score of BOTH
