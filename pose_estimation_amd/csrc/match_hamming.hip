@@ -325,7 +325,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 
 template <int QT>
-__global__ __launch_bounds__(256, 2) void hamming_fp4_dma_kernel(
+__global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
     const uint4* __restrict__ dq, const uint4* __restrict__ img, int tiles,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int splits, int rows_per_split,
@@ -470,8 +470,9 @@ __global__ __launch_bounds__(256, 2) void hamming_fp4_dma_kernel(
 struct HammingMfmaPlan { int qt, splits, rows_per_split, tiles; size_t off_img, total; };
 HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
     HammingMfmaPlan p;
-    const long target = 512;                                   // two 4-wave blocks per CU
-    p.qt = 2;                                                  // 4 measured the same and spills 30 VGPRs
+    const long target = 1024;                                  // four 4-wave blocks per CU
+    p.qt = 1;      // one column tile per wave at 4 waves per SIMD (115 VGPR): 4.0 ms where two tiles at 2 waves take 4.4 —
+                   // matrix and vector instructions of a SIMD do not overlap, more waves fill the gaps between them
     while (p.qt > 1 && (long)B * ph_ceil_div(nq, 128 * p.qt) < target) p.qt >>= 1;
     const long blocks = (long)B * ph_ceil_div(nq, 128 * p.qt);
     int s = (int)((target + blocks - 1) / blocks);
