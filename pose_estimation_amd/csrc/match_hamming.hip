@@ -1,18 +1,19 @@
-// match_hamming.hip — brute-force 256-bit Hamming matcher, nearest + second nearest.
+// match_hamming.hip — brute-force 256-bit Hamming matcher, nearest + second nearest, on the matrix cores.
 // SURVEY.md §8 row a-9 (no reference code; contract in include/posehot.h).
 //
-// Layout of the work (one launch, B pairs):
-//   grid = (ceil(nq / (256*QPT)), splits, B), block = 256 threads = 4 waves.
-//   Every thread keeps QPT query descriptors (8 dwords each) in registers.  Train descriptors
-//   are staged through LDS in tiles of TT rows (register-prefetched double buffer); inside a
-//   tile every lane reads the SAME train row, so the two ds_read_b128 per row are broadcasts.
-//   Per (query, train) pair the VALU work is 8 xor + 8 popcount-accumulate (a 64-bit popcount
-//   is two 32-bit v_bcnt on this ISA) + 3 for the packed top-2 update:
-//       key = (distance << 22) + train_index      (one v_lshl_add_u32)
-//       m2  = med3(m1, m2, key);  m1 = min(m1, key)
-//   The key orders lexicographically by (distance, index): ties go to the lowest index.
-//   When the train set is split over blockIdx.y (few pairs, large sets) every split writes its
-//   (m1, m2) pair to the workspace and a second tiny kernel merges them.
+// For 0/1 vectors  d(q, t) = |q| + |t| - 2 q.t, so the matcher is a GEMM: a descriptor bit becomes a 4-bit float
+// (e2m1: 1.0 in train rows, 2.0 in query rows, block scales 1.0) and v_mfma_scale_f32_32x32x64_f8f6f4 accumulates
+// S = 2 q.t - |t|  on top of a C operand preset to -|t| per train row — at most 256 exact products, exact in f32.
+// For one query, min d <=> max S.  The accumulator has the query on the lane and 16 train rows in the lane's
+// registers (same orientation as the L2 matcher), so top-2 is an in-lane scan in increasing row order (ties -> lowest
+// index); a tile is scanned only if some lane's tile maximum beats the query's current runner-up.
+//   grid = (ceil(nq / 128), splits, B), block = 256 threads = 4 waves, one 32-query column tile per wave.
+//   hamming_expand_kernel prepares the pair's train view once (LDS tile images), the matcher streams them by LDS-DMA.
+// Results travel as keys (distance << 22) + train_index, which order lexicographically by (distance, index).  When the
+// train set is split over blockIdx.y (few pairs, large sets) every split writes its two keys to the workspace and
+// hamming_merge_kernel merges them.
+// Earlier generations of this kernel (8 xor + 8 popcount VALU ops per pair: 16.6 ms at 28 pairs of 32 768^2; int8
+// MFMA with in-kernel expansion: 5.84 ms; this one: 4.0 ms) are in the git history.
 #include "common.hpp"
 
 namespace {
@@ -20,7 +21,6 @@ namespace {
 constexpr int kIdxBits = 22;                      // train rows per view < 2^22
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1;
 constexpr uint32_t kNoKey = 0xffffffffu;
-constexpr int kTT = 128;                          // train rows per LDS tile (4 KiB)
 
 __device__ __forceinline__ void top2_insert(uint32_t& m1, uint32_t& m2, uint32_t key) {
     uint32_t med;                                  // m1 <= m2 always: med3 = new second-best
@@ -35,239 +35,11 @@ __device__ __forceinline__ void emit(uint32_t m1, uint32_t m2, int32_t* idx, int
     d2[o] = (m2 == kNoKey) ? PH_HAMMING_NONE : (int32_t)(m2 >> kIdxBits);
 }
 
-template <int QPT>
-__global__ __launch_bounds__(256) void hamming_top2_kernel(
-    const uint4* __restrict__ dq, const uint4* __restrict__ dt,
-    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
-    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
-    int nq, int nt, int splits, int rows_per_split,
-    int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
-    uint2* __restrict__ partial) {
-    __shared__ uint4 tile[2][kTT * 2];
-
-    const int tid = threadIdx.x;
-    const int b = blockIdx.z, split = blockIdx.y;
-    const int q0 = blockIdx.x * (256 * QPT);
-    const int vq = view_q ? view_q[b] : b;
-    const int vt = view_t ? view_t[b] : b;
-    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
-    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
-    const uint4* Q = dq + (size_t)vq * nq * 2;
-    const uint4* T = dt + (size_t)vt * nt * 2;
-
-    uint64_t qr[QPT][4];
-#pragma unroll
-    for (int p = 0; p < QPT; ++p) {
-        const int qi = q0 + p * 256 + tid;
-        uint4 a = make_uint4(0, 0, 0, 0), c = a;
-        if (qi < nqv) { a = Q[(size_t)qi * 2]; c = Q[(size_t)qi * 2 + 1]; }
-        qr[p][0] = ((uint64_t)a.y << 32) | a.x; qr[p][1] = ((uint64_t)a.w << 32) | a.z;
-        qr[p][2] = ((uint64_t)c.y << 32) | c.x; qr[p][3] = ((uint64_t)c.w << 32) | c.z;
-    }
-    uint32_t m1[QPT], m2[QPT];
-#pragma unroll
-    for (int p = 0; p < QPT; ++p) { m1[p] = kNoKey; m2[p] = kNoKey; }
-
-    const int t_begin = split * rows_per_split;
-    const int t_end = min(ntv, t_begin + rows_per_split);
-
-    // thread `tid` stages 16 B: half (tid & 1) of tile row (tid >> 1)
-    auto fetch = [&](int t0) -> uint4 {
-        const int row = t0 + (tid >> 1);
-        return (row < t_end) ? T[(size_t)row * 2 + (tid & 1)] : make_uint4(0, 0, 0, 0);
-    };
-
-    if (t_begin < t_end) {
-        uint4 stage = fetch(t_begin);
-        int cur = 0;
-        for (int t0 = t_begin; t0 < t_end; t0 += kTT) {
-            tile[cur][tid] = stage;
-            __syncthreads();                       // tile[cur] visible; tile[cur^1] free again
-            if (t0 + kTT < t_end) stage = fetch(t0 + kTT);
-            const int rows = min(kTT, t_end - t0);
-            const uint4* tl = tile[cur];
-#pragma unroll 4
-            for (int r = 0; r < rows; ++r) {
-                const uint4 a = tl[2 * r], c = tl[2 * r + 1];   // wave-uniform address: broadcast
-                const uint64_t w0 = ((uint64_t)a.y << 32) | a.x, w1 = ((uint64_t)a.w << 32) | a.z;
-                const uint64_t w2 = ((uint64_t)c.y << 32) | c.x, w3 = ((uint64_t)c.w << 32) | c.z;
-                const uint32_t j = (uint32_t)(t0 + r);
-#pragma unroll
-                for (int p = 0; p < QPT; ++p) {
-                    const uint32_t d = __popcll(qr[p][0] ^ w0) + __popcll(qr[p][1] ^ w1) +
-                                       __popcll(qr[p][2] ^ w2) + __popcll(qr[p][3] ^ w3);
-                    top2_insert(m1[p], m2[p], (d << kIdxBits) + j);
-                }
-            }
-            cur ^= 1;
-        }
-    }
-
-#pragma unroll
-    for (int p = 0; p < QPT; ++p) {
-        const int qi = q0 + p * 256 + tid;
-        if (qi >= nq) continue;
-        if (qi >= nqv) { m1[p] = kNoKey; m2[p] = kNoKey; }
-        if (splits == 1) emit(m1[p], m2[p], idx, d1, d2, (size_t)b * nq + qi);
-        else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(m1[p], m2[p]);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Matrix-core path.  For 0/1 vectors  d(q, t) = |q| + |t| - 2 q.t, so the Hamming matcher is an integer GEMM:
-// descriptor bits are expanded to bytes (train rows 0/1 into LDS, query rows 0/2 into registers) and
-// v_mfma_i32_32x32x32_i8 accumulates  S = 2 q.t - |t|  on top of a C operand preset to -|t| per train row.  For one
-// query, min d <=> max S, exactly (integers).  The accumulator has the query on the lane and 16 train rows in the
-// lane's registers (same orientation as the L2 matcher), so top-2 is an in-lane scan in increasing row order; a tile
-// is scanned only if some lane's tile maximum beats its current runner-up, which after the first few tiles is rare.
-// Work per descriptor pair: 256 int8 MACs on the matrix core instead of 8 xor + 8 popcount + 3 top-2 VALU ops.
-// ---------------------------------------------------------------------------------------------
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMR = 32;                           // train rows per MFMA tile
-constexpr int kNoScore = -(1 << 30);
 
-// 16 descriptor bits -> 16 bytes (one per bit), bit i in byte i; `one` = 0x01010101 (train) or 0x02020202 (query)
-__device__ __forceinline__ uint4 expand16(uint32_t hw, uint32_t one) {
-    uint32_t d[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const uint32_t spread = (((hw >> (4 * g)) & 0xFu) * 0x00204081u) & 0x01010101u;   // bits 0..3 -> bytes 0..3
-        d[g] = spread * (one & 0xFFu);
-    }
-    return make_uint4(d[0], d[1], d[2], d[3]);
-}
-// plain C++ on purpose: the operands are fresh MFMA results, and the compiler only pads the MFMA -> VALU read
-// hazard for instructions it can see into (inline asm reading the accumulator right after the last MFMA read stale
-// registers).  Both forms are matched to v_med3_i32 / v_max3_i32.
-__device__ __forceinline__ int med3_i32(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }
-__device__ __forceinline__ int max3_i32(int a, int b, int c) { return max(max(a, b), c); }
-
-template <int QT>
-__global__ __launch_bounds__(256, 2) void hamming_mfma_kernel(
-    const uint4* __restrict__ dq, const uint32_t* __restrict__ dt,
-    const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
-    const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
-    int nq, int nt, int splits, int rows_per_split,
-    int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
-    uint2* __restrict__ partial) {
-    __shared__ uint4 tile[2][kMR * 16];           // 32 rows x 256 expanded bytes, 16-byte chunk c of row r at c ^ (r & 15)
-    __shared__ int4 tneg[2][kMR / 4];             // -|t| per row (the C operand); padded rows: kNoScore
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, split = blockIdx.y;
-    const int vq = view_q ? view_q[b] : b;
-    const int vt = view_t ? view_t[b] : b;
-    const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
-    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
-    const uint4* Q = dq + (size_t)vq * nq * 2;
-    const uint32_t* T = dt + (size_t)vt * nt * 8;
-    const int qw0 = (blockIdx.x * 4 + wave) * (32 * QT);
-
-    // B fragments: k-step s of lane half h covers descriptor bits 32s + 16h .. +15
-    uint4 bq[QT][8];
-    int pq[QT], m1[QT], m2[QT], bi[QT];
-#pragma unroll
-    for (int ct = 0; ct < QT; ++ct) {
-        const int qi = qw0 + ct * 32 + li;
-        uint4 a = make_uint4(0, 0, 0, 0), c = a;
-        if (qi < nqv) { a = Q[(size_t)qi * 2]; c = Q[(size_t)qi * 2 + 1]; }
-        const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-        pq[ct] = 0;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            bq[ct][s] = expand16((w[s] >> (16 * h)) & 0xFFFFu, 0x02020202u);
-            pq[ct] += __popc(w[s]);
-        }
-        m1[ct] = kNoScore; m2[ct] = kNoScore; bi[ct] = PH_NO_INDEX;
-    }
-
-    const int t_begin = split * rows_per_split;
-    const int t_end = min(ntv, t_begin + rows_per_split);
-
-    // thread tid stages dword (tid & 7) of tile row (tid >> 3): 32 bits -> two 16-byte chunks
-    const int srow = tid >> 3, spart = tid & 7;
-    auto fetch = [&](int t0) -> uint32_t { return (t0 + srow < t_end) ? T[(size_t)(t0 + srow) * 8 + spart] : 0u; };
-    auto commit = [&](int buf, uint32_t wd, int t0) {
-        tile[buf][srow * 16 + ((2 * spart) ^ (srow & 15))] = expand16(wd & 0xFFFFu, 0x01010101u);
-        tile[buf][srow * 16 + ((2 * spart + 1) ^ (srow & 15))] = expand16(wd >> 16, 0x01010101u);
-        int pc = __popc(wd);
-        pc += __shfl_xor(pc, 1); pc += __shfl_xor(pc, 2); pc += __shfl_xor(pc, 4);
-        if (spart == 0) ((int*)tneg[buf])[srow] = (t0 + srow < t_end) ? -pc : kNoScore;
-    };
-    auto scan = [&](const i32x16& acc, int ct, int t0) {
-        int mx = max3_i32(acc[0], acc[1], acc[2]);
-#pragma unroll
-        for (int r = 3; r < 15; r += 2) mx = max3_i32(mx, acc[r], acc[r + 1]);
-        mx = max(mx, acc[15]);
-        if (__builtin_amdgcn_ballot_w64(mx > m2[ct]) == 0ull) return;
-        const int jb = t0 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {           // increasing row index: strict '>' keeps the lowest index
-            const int v = acc[r];
-            const bool gt = v > m1[ct];
-            m2[ct] = med3_i32(m1[ct], m2[ct], v);
-            m1[ct] = gt ? v : m1[ct];
-            bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
-        }
-    };
-
-    if (t_begin < t_end) {
-        uint32_t stage = fetch(t_begin);
-        int cur = 0;
-        for (int t0 = t_begin; t0 < t_end; t0 += kMR) {
-            commit(cur, stage, t0);
-            __syncthreads();                       // tile[cur] visible; tile[cur^1] free again
-            if (t0 + kMR < t_end) stage = fetch(t0 + kMR);
-            i32x16 acc[QT];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int4 z = tneg[cur][2 * g + h];   // rows 8g + 4h .. +3
-                acc[0][4 * g + 0] = z.x; acc[0][4 * g + 1] = z.y; acc[0][4 * g + 2] = z.z; acc[0][4 * g + 3] = z.w;
-            }
-#pragma unroll
-            for (int ct = 1; ct < QT; ++ct) acc[ct] = acc[0];
-            const uint4* trow = &tile[cur][li * 16];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const i32x4 a = __builtin_bit_cast(i32x4, trow[(2 * s + h) ^ (li & 15)]);
-#pragma unroll
-                for (int ct = 0; ct < QT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, __builtin_bit_cast(i32x4, bq[ct][s]), acc[ct], 0, 0, 0);
-            }
-#pragma unroll
-            for (int ct = 0; ct < QT; ++ct) scan(acc[ct], ct, t0);
-            cur ^= 1;
-        }
-    }
-
-    // merge the two lane halves (same query, disjoint train rows), then emit distances d = |q| - S
-#pragma unroll
-    for (int ct = 0; ct < QT; ++ct) {
-        const int om1 = __shfl_xor(m1[ct], 32), om2 = __shfl_xor(m2[ct], 32), obi = __shfl_xor(bi[ct], 32);
-        const bool other = (om1 > m1[ct]) || (om1 == m1[ct] && obi >= 0 && (bi[ct] < 0 || obi < bi[ct]));
-        const int lost = other ? m1[ct] : om1;
-        const int nm2 = max(lost, max(m2[ct], om2));
-        const int nm1 = other ? om1 : m1[ct];
-        const int nbi = other ? obi : bi[ct];
-        const int qi = qw0 + ct * 32 + li;
-        if (h != 0 || qi >= nq) continue;
-        uint32_t k1 = kNoKey, k2 = kNoKey;
-        if (qi < nqv && nbi >= 0) {
-            k1 = ((uint32_t)(pq[ct] - nm1) << kIdxBits) + (uint32_t)nbi;
-            if (nm2 != kNoScore) k2 = ((uint32_t)(pq[ct] - nm2) << kIdxBits) + kIdxMask;   // runner-up: distance only
-        }
-        if (splits == 1) emit(k1, k2, idx, d1, d2, (size_t)b * nq + qi);
-        else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(k1, k2);
-    }
-}
-
-// ---- the same matcher on the block-scaled fp4 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e2m1 operands, scales 1.0):
-// twice the K per instruction at the cycles of the int8 form, so half the matrix instructions and half the LDS bytes.
-// A bit becomes a 4-bit float: 1.0 (0x2) in train rows, 2.0 (0x4) in query rows; products and the f32 accumulation of
-// at most 256 of them on top of -|t| are exact, so S = 2 q.t - |t| is the same integer the int8 kernel computes.  The
-// order of K inside a lane does not matter as long as both operands are expanded by the same function (they are).
+// The block-scaled fp4 MFMA takes twice the K per instruction at the cycles of the int8 form: half the matrix
+// instructions and half the LDS bytes of an int8 formulation.  1.0 is 0x2 and 2.0 is 0x4 in e2m1.  The order of K inside
+// a lane does not matter as long as both operands are expanded by the same function (they are).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float kNoScoreF = -1.0e9f;              // exactly representable; padded rows are all-zero, so they keep it
@@ -511,26 +283,6 @@ __global__ __launch_bounds__(256) void ratio_hamming_kernel(const int32_t* __res
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     keep[i] = (idx[i] >= 0 && d2[i] != PH_HAMMING_NONE && (float)d1[i] < ratio * (float)d2[i]) ? 1 : 0;
-}
-
-// how to cut one launch: queries per thread and train splits, from the amount of work.
-struct HammingPlan { int qpt, splits, rows_per_split; };
-HammingPlan plan_hamming(int B, int nq, int nt) {
-    HammingPlan p;
-    const long waves_target = 256L * 4 * 4;                    // ~4 waves per SIMD over the chip
-    p.qpt = 4;
-    while (p.qpt > 1 && (long)B * ph_ceil_div(nq, 256 * p.qpt) * 4 < waves_target) p.qpt >>= 1;
-    const long blocks = (long)B * ph_ceil_div(nq, 256 * p.qpt);
-    int s = (int)((waves_target / 4 + blocks - 1) / blocks);
-    const int max_s = ph_ceil_div(nt, 4 * kTT);                // at least 4 tiles per split
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    p.rows_per_split = ph_ceil_div(ph_ceil_div(nt, s), kTT) * kTT;
-    if (p.rows_per_split < kTT) p.rows_per_split = kTT;
-    p.splits = ph_ceil_div(nt, p.rows_per_split);
-    if (p.splits < 1) p.splits = 1;
-    return p;
 }
 
 }  // namespace
