@@ -45,6 +45,7 @@ constexpr int kCPR = kDim / 8;  // 16-byte fp16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
 constexpr int kCapH = 32;      // list entries per (query, split, lane half)
 constexpr int kBlocksPerCU = 2;
+constexpr int kDepth = 2;         // staged tiles copied ahead of the one being worked on (3: same time; 4: slower)
 constexpr int kPrimeRows = 512;   // rows of the priming pass (per split)
 
 // ---- per-pair scales and the error band (one definition for the three kernels) -------------------------------------
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
     static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256, "staging deal");
-    __shared__ uint4 smem[3 * kImg];              // ring of three staged tiles; ONE array: a second LDS object beside an LDS-DMA
+    __shared__ uint4 smem[(kDepth + 1) * kImg];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,36 +272,42 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         }
     };
 
-    // priming: running top-2 of the approximate scores, nothing appended
-    auto prime = [&](const f32x16& acc, int ct) {
+    // The bound is tracked on TILE MAXIMA: (a1, a2) = the two largest per-tile maxima this lane has seen.  Two tiles
+    // are two different rows, so a2 is a lower bound of the lane's second-largest score — nearly as tight as the
+    // element-wise one (it differs only when a lane's two best rows share a tile), at two instructions per tile,
+    // without branches, instead of four per appended row inside a divergent block.
+    auto tile_max = [&](const f32x16& acc, float (&m4)[4]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = acc[r];
-            a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], v);
-            a1[ct] = fmaxf(a1[ct], v);
-        }
+        for (int i = 0; i < 4; ++i) m4[i] = vmax(vmax(acc[4 * i], acc[4 * i + 1]), vmax(acc[4 * i + 2], acc[4 * i + 3]));
+        return vmax(vmax(m4[0], m4[1]), vmax(m4[2], m4[3]));
+    };
+    auto track = [&](float m, int ct) {
+        a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], m);
+        a1[ct] = vmax(a1[ct], m);
+    };
+    // priming: nothing appended
+    auto prime = [&](const f32x16& acc, int ct) {
+        float m4[4];
+        track(tile_max(acc, m4), ct);
     };
     // filtering: rows whose approximate score reaches the bound are appended.  The 16 accumulator registers are
-    // reduced in four groups of four (v_max3); a group is entered only if some lane of the wave has a hit in it, so a
-    // tile with one hit costs 1 + 4 wave-level tests and 4 masked blocks instead of 16.  thr only rises while rows are appended,
-    // and every test uses the current value.
+    // reduced in four groups of four; a group is entered only if some lane of the wave has a hit in it, so a tile
+    // with one hit costs 1 + 4 wave-level tests and 4 masked blocks instead of 16.  All tests of a tile use the bound
+    // at its entry (an older, lower bound appends a superset).
     // A list entry is (row - 4h, sA): the row without the lane half's offset is wave-uniform (a scalar), and the half
     // is implied by the segment the entry sits in (the re-rank adds it back).
     auto hit = [&](float v, int jrow, int ct) {
         if (v >= thr[ct]) {
             if (nc[ct] < kCapH) lp[ct][nc[ct]] = make_int2(jrow, __float_as_int(v));
             ++nc[ct];
-            a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], v);
-            a1[ct] = vmax(a1[ct], v);
-            thr[ct] = vmax(thr[ct], a2[ct] - eps2[ct]);
         }
     };
     auto any_ge = [&](float m, int ct) { return __builtin_amdgcn_ballot_w64(m >= thr[ct]) != 0ull; };
     auto filter = [&](const f32x16& acc, int ct, int t0) {
         float m4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) m4[i] = vmax(vmax(acc[4 * i], acc[4 * i + 1]), vmax(acc[4 * i + 2], acc[4 * i + 3]));
-        if (!any_ge(vmax(vmax(m4[0], m4[1]), vmax(m4[2], m4[3])), ct)) return;
+        const float m = tile_max(acc, m4);
+        track(m, ct);
+        if (!any_ge(m, ct)) return;
         const int t0s = __builtin_amdgcn_readfirstlane(t0);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -315,31 +322,38 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         thr[ct] = vmax(vmax(thr[ct], ot), second - eps2[ct]);
     };
 
-    // Staging pipeline: a ring of three LDS buffers, one barrier per staged tile, copies two tiles ahead.  At the top
-    // of iteration `it` every wave has waited for its own share of tile `it` and the barrier makes the whole image
-    // visible (and tells that everybody is done reading tile it-1, whose buffer the copy of tile it+2 now overwrites).
+    // Staging pipeline: a ring of kDepth + 1 LDS buffers, one barrier per staged tile, copies kDepth tiles ahead.  At
+    // the top of iteration `it` every wave has waited for its own share of tile `it` and the barrier makes the whole
+    // image visible (and tells that everybody is done reading tile it-1, whose buffer the newest copy now overwrites).
     // The MFMA chains of all sub-tiles run first; then the wave waits for its share of tile it+1 — a counted wait that
-    // leaves the kGlds copies of tile it+2 in flight (the counter retires in issue order, and the list stores of the
-    // previous iteration are older than those copies) — and only then appends candidates, so no wait ever sees a
-    // young store.
+    // leaves the copies of the tiles behind it in flight (the counter retires in issue order) — and then appends
+    // candidates.
     constexpr int kGlds = kImgRows / 256 + 1;        // LDS-DMA instructions per wave per staged tile
+    // waits for this wave's share of the tile `ahead` tiles behind the newest copy: everything older than the last
+    // `ahead` tiles' copies has retired — the copies of the wanted tile AND every list store issued before them
+    auto wait_ahead = [&](int ahead) {
+        static_assert(kDepth <= 4, "one case per possible count below");
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kGlds) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kGlds) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     const int n_iter = n_prime + n_tiles;
     auto tile_of = [&](int it) { return t_begin / kSR + (it < n_prime ? it : it - n_prime); };
-    stage(tile_of(0), 0);
-    if (n_iter > 1) { stage(tile_of(1), 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    int cur = 0, nxt2 = 2;
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (d < n_iter) stage(tile_of(d), d);
+    wait_ahead(min(kDepth, n_iter) - 1);
+    int cur = 0, nxt = kDepth;
     for (int it = 0; it < n_iter; ++it) {
         const bool priming = it < n_prime;
         const int t0 = tile_of(it) * kSR;
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const bool more = it + 2 < n_iter;
-        if (more) stage(tile_of(it + 2), nxt2);
+        if (it + kDepth < n_iter) stage(tile_of(it + kDepth), nxt);
         f32x16 acc[kSub][kQT];
         tile_scores(cur, acc);
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_ahead(min(kDepth, n_iter - 1 - it) - 1 < 0 ? 0 : min(kDepth, n_iter - 1 - it) - 1);   // tile it+1 landed
 #pragma unroll
         for (int sub = 0; sub < kSub; ++sub) {
             if (priming) {
@@ -361,8 +375,8 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
                 a1[ct] = -INFINITY; a2[ct] = -INFINITY;
             }
         }
-        cur = cur == 2 ? 0 : cur + 1;
-        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        cur = cur == kDepth ? 0 : cur + 1;
+        nxt = nxt == kDepth ? 0 : nxt + 1;
     }
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct)
