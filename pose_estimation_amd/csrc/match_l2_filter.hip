@@ -35,6 +35,7 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTR = 32;       // train rows per MFMA tile
 constexpr int kSub = 2;       // MFMA tiles per staged tile (one barrier per staged tile)
@@ -199,6 +200,9 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     const float Tm = tqmax[b], Qm = tqmax[B + b];
     const PairScale sc = pair_scale(Tm, Qm);
     const uint4* IMG = img + (size_t)b * tiles * kImg;
+    // the pair's candidate lists as a raw buffer (at most 4 GB per pair: nq * slots * 256 bytes)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        list + (size_t)b * nq * slots * kCapH, 0, (int)((size_t)nq * slots * kCapH * sizeof(int2)), 0x00020000);
 
     const int qw0 = xb * (NT / 64) * (32 * kQT) + wave * (32 * kQT);   // first query of this wave
 
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     uint4 bh[kQT][kNS];
     float thr[kQT], eps2[kQT], a1[kQT], a2[kQT];
     size_t qoff[kQT];
-    int2* lp[kQT];                                   // this lane's private list segment
+    unsigned lbase[kQT];                             // byte offset of this lane's private list segment in the pair's lists
     int nc[kQT];                                     // entries in it
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct) {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         for (int s = 0; s < kNS; ++s) bh[ct][s] = to_f16x8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], sc.sq);
         const bool live = qi < nqv;
         qoff[ct] = ((size_t)b * nq + min(qi, nq - 1)) * slots + (2 * split + h);
-        lp[ct] = list + qoff[ct] * kCapH;
+        lbase[ct] = (unsigned)(((size_t)min(qi, nq - 1) * slots + (2 * split + h)) * kCapH * sizeof(int2));
         nc[ct] = 0;
         eps2[ct] = band2_scaled(QN[min(qi, nq - 1)], Tm, Qm, sc.s);
         thr[ct] = live ? -3.0e38f : INFINITY;           // finite floor: the -inf score of a padded row never reaches it;
@@ -296,11 +300,15 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     // at its entry (an older, lower bound appends a superset).
     // A list entry is (row - 4h, sA): the row without the lane half's offset is wave-uniform (a scalar), and the half
     // is implied by the segment the entry sits in (the re-rank adds it back).
+    // The append is a raw buffer store whose offset is moved out of the buffer's range for lanes without a hit (the
+    // hardware drops out-of-range lanes): no exec mask, no branch — a block that holds a memory instruction keeps its
+    // skip branch, and those branches, not the instructions, were what the slow path cost.
     auto hit = [&](float v, int jrow, int ct) {
-        if (v >= thr[ct]) {
-            if (nc[ct] < kCapH) lp[ct][nc[ct]] = make_int2(jrow, __float_as_int(v));
-            ++nc[ct];
-        }
+        const bool c = v >= thr[ct];
+        const unsigned off = (c && nc[ct] < kCapH) ? lbase[ct] + 8u * (unsigned)nc[ct] : 0xffffffffu;
+        const i32x2 d = {jrow, __float_as_int(v)};
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off, 0, 0);
+        nc[ct] += c ? 1 : 0;
     };
     auto any_ge = [&](float m, int ct) { return __builtin_amdgcn_ballot_w64(m >= thr[ct]) != 0ull; };
     auto filter = [&](const f32x16& acc, int ct, int t0) {
@@ -312,8 +320,17 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             if (!any_ge(m4[g4], ct)) continue;
+            // one append per entered group: the lane's largest of the four (a lane with a hit has, as a rule, one)
+            const float a = acc[4 * g4], b = acc[4 * g4 + 1], c = acc[4 * g4 + 2], d = acc[4 * g4 + 3], mg = m4[g4];
+            int k = (d == mg) ? 3 : 0;
+            k = (c == mg) ? 2 : k; k = (b == mg) ? 1 : k; k = (a == mg) ? 0 : k;
+            hit(mg, t0s + 8 * g4 + k, ct);
+            // a second row of the same four reaching the bound (second-largest of the four): the other three one by one
+            const float second = vmax(fminf(vmax(a, b), vmax(c, d)), vmax(fminf(a, b), fminf(c, d)));
+            if (any_ge(second, ct)) {
 #pragma unroll
-            for (int r = 4 * g4; r < 4 * g4 + 4; ++r) hit(acc[r], t0s + (r & 3) + 8 * (r >> 2), ct);
+                for (int r = 0; r < 4; ++r) hit(r == k ? -INFINITY : acc[4 * g4 + r], t0s + 8 * g4 + r, ct);
+            }
         }
         // the other lane half holds the same query (its other rows): the second-largest of the union of the two
         // halves' top-2 is the tighter bound — half of the time the best two rows sit in different halves
