@@ -29,7 +29,7 @@ from pose_estimation_amd import matching, pipeline, synthetic  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 1024 SIMDs x 32768 FLOP / 32 cyc x 2.4 GHz
-L2_CALL_HBM_BYTES_AT_32_PAIRS = 848.0e6   # (1.1 + 66.3 + 100.0 + 169.9) MB FETCH_SIZE x 2 + (2.1 + 67.6 + 100.8 + 3.1) MB WRITE_SIZE
+L2_CALL_HBM_BYTES_AT_32_PAIRS = 816.0e6   # (1.1 + 66.3 + 100.0 + 168.8) MB FETCH_SIZE x 2 + (2.1 + 67.6 + 71.3 + 3.2) MB WRITE_SIZE
 N_FEAT, DIM = 8192, 128
 N_SAMPLES = 410                 # minimal samples per pair; the 5-point solver fills 10 hypothesis slots each
 N_HYP = 10 * N_SAMPLES          # 4100 essential-matrix hypotheses scored per pair (>= the 4096 of configs[1])
@@ -214,7 +214,7 @@ def main():
         roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
                     "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_F16_MFMA_TFLOPS,
-                    # HBM bytes per launch, rocprofv3 --pmc offline (profiles/r1/l2_filter_f16_pmc_summary.json): FETCH_SIZE x2
+                    # HBM bytes per launch, rocprofv3 --pmc offline (profiles/r1/l2_filter_f16_v9_traffic_pmc_summary.json): FETCH_SIZE x2
                     # (gfx950 correction) + WRITE_SIZE over the four kernels of the call at 32 pairs; scaled by pairs
                     "traffic": L2_CALL_HBM_BYTES_AT_32_PAIRS * P / 32, "launch_ms": kern_ms, "isolated_launch_ms": iso_ms,
                     "isolated_achieved": flops / (iso_ms * 1e-3) / 1e12,
