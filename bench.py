@@ -105,15 +105,28 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # POSEHOT_BENCH_FORCE_DIST=1 takes the collective path at world size 1 too (rehearsal of the N > 1 code on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("POSEHOT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     P = args.pairs
     batch = make_batch(P, rank, dev)
     thr_sq = float(np.float32((THR_PX / synthetic.FX) ** 2))
-    gathered = torch.empty((world * P, 16), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * P, 16), dtype=torch.float32, device=dev) if use_dist else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     state = {"step": -1}
 
@@ -146,7 +159,7 @@ def main():
 
     def back(f):
         out = pipeline.relative_pose_back(f)
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(gathered, out["table"])
         return out
 
@@ -174,7 +187,7 @@ def main():
         return out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -185,7 +198,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     state["step"] = -1
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -256,7 +269,9 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads, out["E_hyp"])
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and not torch.equal(gathered[:P], out["table"]):
+            raise SystemExit("gathered pose table does not hold this rank's rows")
         dist.destroy_process_group()
 
 
