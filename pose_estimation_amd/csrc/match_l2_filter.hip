@@ -282,8 +282,8 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
     // without branches, instead of four per appended row inside a divergent block.
     auto tile_max = [&](const f32x16& acc, float (&m4)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m4[i] = vmax(vmax(acc[4 * i], acc[4 * i + 1]), vmax(acc[4 * i + 2], acc[4 * i + 3]));
-        return vmax(vmax(m4[0], m4[1]), vmax(m4[2], m4[3]));
+        for (int i = 0; i < 4; ++i) m4[i] = vmax(vmax(vmax(acc[4 * i], acc[4 * i + 1]), acc[4 * i + 2]), acc[4 * i + 3]);   // v_max3 + v_max
+        return vmax(vmax(vmax(m4[0], m4[1]), m4[2]), m4[3]);
     };
     auto track = [&](float m, int ct) {
         a2[ct] = __builtin_amdgcn_fmed3f(a1[ct], a2[ct], m);
