@@ -82,3 +82,73 @@ def test_hamming_fuzz_against_oracle(device, seed):
         assert np.array_equal(idx[b, :n_q[b]], ri), b
         assert np.array_equal(d1[b, :n_q[b]], r1), b
         assert np.array_equal(d2[b, :n_q[b]], r2), b
+
+
+def _check_bailout(cnt, ref):
+    assert (cnt <= ref).all()
+    for b in range(ref.shape[0]):
+        bi, bc = orc.select_best(ref[b])
+        assert cnt[b].max() == bc and int(cnt[b].argmax()) == bi
+        assert np.array_equal(cnt[b][ref[b] == bc], ref[b][ref[b] == bc])
+
+
+@pytest.mark.parametrize("seed", range(12 + _MORE // 8))
+def test_scoring_fuzz_against_oracle(device, seed):
+    """Random (B, H, N, n_valid) shapes — one and several point splits, tail waves, empty slots, duplicated best
+    hypotheses — for both residuals: exhaustive counts, bail-out winners and the winner's inlier words."""
+    from pose_estimation_amd import ransac
+    rng = np.random.default_rng(9000 + seed)
+    B = int(rng.integers(1, 6)); H = int(rng.choice([1, 7, 32, 33, 500, 1024, 2300])); N = int(rng.choice([1, 63, 64, 513, 1500, 6000]))
+    n_valid = rng.integers(0, N + 1, B).astype(np.int32); n_valid[0] = N
+    # essential matrices: random unit 9-vectors, a few near the truth of a synthetic pair, some empty slots, one duplicate
+    sc = synthetic.two_view_pair(n=max(N, 8), seed=100 + seed)
+    pr = sc["partner"]; ok = pr >= 0
+    x1, y1 = sc["kp1"][:N, 0].copy(), sc["kp1"][:N, 1].copy()
+    x2, y2 = x1.copy(), y1.copy()
+    okn = ok[:N]
+    x2[okn], y2[okn] = sc["kp2"][pr[:N][okn], 0], sc["kp2"][pr[:N][okn], 1]
+    pts = [np.tile(a, (B, 1)).astype(np.float32) for a in (x1, y1, x2, y2)]
+    for a in pts:
+        a += rng.normal(0, 1e-4, a.shape).astype(np.float32) * (np.arange(B)[:, None] > 0)
+    Et = synthetic.essential_from_pose(sc["R"], sc["t"]).reshape(9); Et /= np.linalg.norm(Et)
+    E = rng.standard_normal((B, H, 9)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=2, keepdims=True)
+    near = rng.choice(H, max(1, H // 5), replace=False)
+    E[:, near] = (Et + rng.standard_normal((B, near.size, 9)) * 0.003).astype(np.float32)
+    E[:, rng.choice(H, max(1, H // 7), replace=False)] = 0.0
+    E[:, H // 2] = Et; E[:, H - 1] = Et
+    thr = np.float32((1.5 / synthetic.FX) ** 2)
+    d = [_t(a, device) for a in pts]
+    nv = _t(n_valid, device)
+    full = ransac.score_essential(_t(E, device), *d, float(thr), nv).cpu().numpy()
+    ref = np.stack([orc.score_essential(E[b], *(a[b][:n_valid[b]] for a in pts), thr) for b in range(B)])
+    assert np.array_equal(full, ref)
+    _check_bailout(ransac.score_essential(_t(E, device), *d, float(thr), nv, bailout=True).cpu().numpy(), ref)
+    bi, _ = ransac.select_best(_t(full, device))
+    words = ransac.inlier_mask_essential(_t(E, device), bi, *d, float(thr), nv).cpu().numpy().view(np.uint64)
+    for b in range(B):
+        m = orc.inlier_mask_essential(E[b, int(bi[b])], *(a[b][:n_valid[b]] for a in pts), thr, N)
+        assert np.array_equal(words[b], m)
+    # PnP
+    fr = synthetic.pnp_frames(B, N, outliers=0.3, noise_px=1.0, seed=300 + seed)
+    K = np.array([[synthetic.FX, 0, synthetic.CX], [0, synthetic.FY, synthetic.CY], [0, 0, 1.0]])
+    P = np.zeros((B, H, 12), np.float32)
+    for b in range(B):
+        base = synthetic.perturbed_poses(rng, fr["R"][b], fr["t"][b], 16, rot_sigma=0.01, t_sigma=0.02)
+        rep = base[rng.integers(0, 16, H)]
+        rep[:, :, 3] += rng.normal(0, 0.03, (H, 3))
+        rep[H // 3] = base[0]; rep[H - 1] = base[0]
+        P[b] = (K @ rep).reshape(H, 12).astype(np.float32)
+    P[:, rng.choice(H, max(1, H // 9), replace=False)] = 0.0
+    q = [np.ascontiguousarray(fr[k], np.float32) for k in "XYZuv"]
+    dq = [_t(a, device) for a in q]
+    thr = np.float32(25.0)
+    full = ransac.score_pnp(_t(P, device), *dq, float(thr), nv).cpu().numpy()
+    ref = np.stack([orc.score_pnp(P[b], *(a[b][:n_valid[b]] for a in q), thr) for b in range(B)])
+    assert np.array_equal(full, ref)
+    _check_bailout(ransac.score_pnp(_t(P, device), *dq, float(thr), nv, bailout=True).cpu().numpy(), ref)
+    bi, _ = ransac.select_best(_t(full, device))
+    words = ransac.inlier_mask_pnp(_t(P, device), bi, *dq, float(thr), nv).cpu().numpy().view(np.uint64)
+    for b in range(B):
+        m = orc.inlier_mask_pnp(P[b, int(bi[b])], *(a[b][:n_valid[b]] for a in q), thr, N)
+        assert np.array_equal(words[b], m)
