@@ -470,24 +470,43 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
 #pragma unroll
     for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + c] = q[c];
 
-    // (2) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound
+    // (2) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound.  The counts and first
+    // cache lines of the first two segments (all there are unless the train rows are split) are loaded in one go and kept
+    // in registers for (3).
     bool overflow = false;
     float p1 = -INFINITY, p2 = -INFINITY;
-    if (live)
-        for (int slot = 0; slot < slots; ++slot) {
+    constexpr int kE = 16 / kRL;                           // entries per lane in the first cache line of a segment
+    int cn[2] = {0, 0};
+    int2 ent[2][kE];
+    auto bump = [&](float v) { p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); };
+    if (live) {
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {             // slots = 2 * splits >= 2
+            cn[slot] = cnt[o * slots + slot];
+#pragma unroll
+            for (int k = 0; k < kE; ++k) ent[slot][k] = list[(o * slots + slot) * kCapH + sl + kRL * k];
+        }
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {
+            overflow |= cn[slot] > kCapH;
+#pragma unroll
+            for (int k = 0; k < kE; ++k)
+                if (sl + kRL * k < cn[slot]) bump(__int_as_float(ent[slot][k].y));
+            for (int k = sl + 16; k < cn[slot] && k < kCapH; k += kRL)    // second cache line: rarely used
+                bump(__int_as_float(list[(o * slots + slot) * kCapH + k].y));
+        }
+        for (int slot = 2; slot < slots; ++slot) {
             const int c = cnt[o * slots + slot];
             overflow |= c > kCapH;
-            int2 e[16 / kRL];                                             // first cache line of the segment (16 entries):
+            int2 e[kE];
 #pragma unroll
-            for (int k = 0; k < 16 / kRL; ++k) e[k] = list[(o * slots + slot) * kCapH + sl + kRL * k];   // issued with the count
+            for (int k = 0; k < kE; ++k) e[k] = list[(o * slots + slot) * kCapH + sl + kRL * k];   // issued with the count
 #pragma unroll
-            for (int k = 0; k < 16 / kRL; ++k)
-                if (sl + kRL * k < c) { const float v = __int_as_float(e[k].y); p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); }
-            for (int k = sl + 16; k < c && k < kCapH; k += kRL) {         // second cache line: rarely used
-                const float v = __int_as_float(list[(o * slots + slot) * kCapH + k].y);
-                p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v);
-            }
+            for (int k = 0; k < kE; ++k)
+                if (sl + kRL * k < c) bump(__int_as_float(e[k].y));
+            for (int k = sl + 16; k < c && k < kCapH; k += kRL) bump(__int_as_float(list[(o * slots + slot) * kCapH + k].y));
         }
+    }
 #pragma unroll
     for (int w = kRL / 2; w > 0; w >>= 1) {
         const float o1 = __shfl_xor(p1, w), o2 = __shfl_xor(p2, w);
@@ -521,11 +540,12 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
                 const int id = lane + 64 * i, r = id >> 5, c = id & 31;
                 if (r < k) L.rows[r * 32 + (c ^ r)] = Tt[(size_t)L.qj[base + r] * (kDim / 4) + c];
             }
+            const float tn = (lane < k) ? TN[L.qj[base + lane]] : 0.0f;    // travels with the rows: no second round trip
             wave_sync();
             if (lane < k) {
-                const int r = lane, jr = L.qj[base + r];
+                const int r = lane;
                 const float4* qr = &L.qrow[L.qq[base + r] * 32];
-                float acc = -0.5f * TN[jr];
+                float acc = -0.5f * tn;
 #pragma unroll 4
                 for (int c = 0; c < 16; ++c) {
                     const float4 q0 = qr[2 * c], q1 = qr[2 * c + 1];
@@ -550,33 +570,49 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     int max_slots = (live && !overflow) ? slots : 0;
     for (int w = 32; w > 0; w >>= 1) max_slots = max(max_slots, __shfl_xor(max_slots, w));
     wave_sync();
-    for (int slot = 0; slot < max_slots; ++slot) {
-        for (int pass = 0; pass < kCapH / kRL; ++pass) {
-            int j = -1;
-            if (live && !overflow) {
-                const int c = min(cnt[o * slots + slot], kCapH);
-                if (sl + kRL * pass < c) {
-                    const int2 e = list[(o * slots + slot) * kCapH + sl + kRL * pass];
-                    if (__int_as_float(e.y) >= bound) j = e.x + 4 * (slot & 1);     // the segment's lane half: rows +4
-                }
-            }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(j >= 0);
-            if (m == 0ull) continue;
-            if (j >= 0) {
-                const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                L.qj[pos] = j; L.qq[pos] = qid;
-            }
-            n += __builtin_popcountll(m);
-            if (n >= kRC) {                                // keep the queue within its 64 + kRC entries
-                wave_sync();
-                const int full = n & ~(kRC - 1);
-                flush(full);
-                if (lane < n - full) { const int a = L.qj[full + lane], c2 = L.qq[full + lane]; wave_sync(); L.qj[lane] = a; L.qq[lane] = c2; }
-                n -= full;
-                wave_sync();
+    // one candidate row per lane (or -1) -> wave queue; flushes whole chunks when the queue reaches kRC entries
+    auto enqueue = [&](int j) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(j >= 0);
+        if (m == 0ull) return;
+        if (j >= 0) {
+            const int pos = n + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+            L.qj[pos] = j; L.qq[pos] = qid;
+        }
+        n += __builtin_popcountll(m);
+        if (n >= kRC) {                                    // keep the queue within its 64 + kRC entries
+            wave_sync();
+            const int full = n & ~(kRC - 1);
+            flush(full);
+            if (lane < n - full) { const int a = L.qj[full + lane], c2 = L.qq[full + lane]; wave_sync(); L.qj[lane] = a; L.qq[lane] = c2; }
+            n -= full;
+            wave_sync();
+        }
+    };
+    const bool use = live && !overflow;
+    auto from_memory = [&](int slot, int pass) {
+        int j = -1;
+        if (use) {
+            const int c = min(cnt[o * slots + slot], kCapH);
+            if (sl + kRL * pass < c) {
+                const int2 e = list[(o * slots + slot) * kCapH + sl + kRL * pass];
+                if (__int_as_float(e.y) >= bound) j = e.x + 4 * (slot & 1);     // the segment's lane half: rows +4
             }
         }
+        enqueue(j);
+    };
+    if (max_slots > 0) {
+#pragma unroll
+        for (int slot = 0; slot < 2; ++slot) {             // the first two segments: out of the registers of (2)
+            const int c = use ? min(cn[slot], kCapH) : 0;
+#pragma unroll
+            for (int k = 0; k < kE; ++k)
+                enqueue((sl + kRL * k < c && __int_as_float(ent[slot][k].y) >= bound) ? ent[slot][k].x + 4 * (slot & 1) : -1);
+            if (__builtin_amdgcn_ballot_w64(c > 16) != 0ull)
+                for (int pass = kE; pass < kCapH / kRL; ++pass) from_memory(slot, pass);
+        }
     }
+    for (int slot = 2; slot < max_slots; ++slot)
+        for (int pass = 0; pass < kCapH / kRL; ++pass) from_memory(slot, pass);
     wave_sync();
     flush(n);
 
