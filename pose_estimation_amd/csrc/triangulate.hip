@@ -109,32 +109,51 @@ __global__ __launch_bounds__(256) void compact_kernel(const int32_t* __restrict_
                                                      float* __restrict__ x2, float* __restrict__ y2,
                                                      int32_t* __restrict__ match_q, int32_t* __restrict__ match_t,
                                                      int32_t* __restrict__ n_match) {
-    __shared__ int wave_tot[4];
+    // 2048 candidates per round, element i0 + 256 u + tid with thread tid in step u: the eight loads of a thread travel
+    // together, so a round costs two memory round trips and two barriers instead of sixteen of each.
+    constexpr int U = 8;
+    __shared__ int wave_tot[U][4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int vq = view_q ? view_q[b] : b, vt = view_t ? view_t[b] : b;
     const float2* KQ = kp_q + (size_t)vq * nq;
     const float2* KT = kp_t + (size_t)vt * nt;
     int base = 0;
-    for (int i0 = 0; i0 < nq; i0 += 256) {
-        const int i = i0 + tid;
-        int j = PH_NO_INDEX;
-        bool k = false;
-        if (i < nq) { j = idx[(size_t)b * nq + i]; k = keep[(size_t)b * nq + i] != 0 && j >= 0 && j < nt; }
-        const unsigned long long bal = __ballot(k);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_tot[w];
-        const int total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-        if (k) {
-            const size_t o = (size_t)b * nq + off + before;
-            const float2 a = KQ[i], t = KT[j];
-            x1[o] = a.x; y1[o] = a.y; x2[o] = t.x; y2[o] = t.y;
-            if (match_q) match_q[o] = i;
-            if (match_t) match_t[o] = j;
+    for (int i0 = 0; i0 < nq; i0 += 256 * U) {
+        int j[U], kp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 256 * u + tid;
+            j[u] = PH_NO_INDEX; kp[u] = 0;
+            if (i < nq) { j[u] = idx[(size_t)b * nq + i]; kp[u] = keep[(size_t)b * nq + i]; }
         }
-        base += total;
+        bool k[U];
+        int before[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            k[u] = kp[u] != 0 && j[u] >= 0 && j[u] < nt;
+            const unsigned long long bal = __ballot(k[u]);
+            before[u] = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_tot[u][wave] = __popcll(bal);
+        }
+        __syncthreads();
+        float2 a[U], t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k[u]) { a[u] = KQ[i0 + 256 * u + tid]; t[u] = KT[j[u]]; }
+        int off = base;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int mine = off;
+            for (int w = 0; w < wave; ++w) mine += wave_tot[u][w];
+            if (k[u]) {
+                const size_t o = (size_t)b * nq + mine + before[u];
+                x1[o] = a[u].x; y1[o] = a[u].y; x2[o] = t[u].x; y2[o] = t[u].y;
+                if (match_q) match_q[o] = i0 + 256 * u + tid;
+                if (match_t) match_t[o] = j[u];
+            }
+            off += wave_tot[u][0] + wave_tot[u][1] + wave_tot[u][2] + wave_tot[u][3];
+        }
+        base = off;
         __syncthreads();
     }
     if (tid == 0) n_match[b] = base;
