@@ -167,7 +167,7 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
+__global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     const float* __restrict__ dq, const uint4* __restrict__ img, int tiles,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
@@ -244,35 +244,29 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         if (lane < kImgTail / 4) glds16(src + kImgRows + wave * (kImgTail / 4) + lane, dst_tail);
     };
 
-    // All A fragments and score presets of a staged tile are read up front (the k-step of one fp16 product is only
-    // kQT MFMAs long: too short to hide an LDS read issued one step ahead), then the MFMA chains run back to back.
-    auto tile_scores = [&](int buf, f32x16 (&acc)[kSub][kQT]) {
-        uint4 af[kSub][kNS];
+    // The two MFMA tiles of a staged tile are worked on one after the other (fragments and presets of a tile are read up
+    // front — the k-step of one fp16 product is only kQT MFMAs long: too short to hide an LDS read issued one step ahead
+    // — then its MFMA chains run back to back, then its scores are filtered): one tile's fragments and accumulators live
+    // at a time keep the kernel at <= 168 VGPR, which leaves the third wave slot of every SIMD to the other kernels of
+    // the step (re-rank, solver, scoring: 120-128 VGPR) when batches overlap on several streams.
+    auto tile_scores = [&](int buf, int sub, f32x16 (&acc)[kQT]) {
+        uint4 af[kNS];
+        const uint4* rh = smem + buf * kImg + sub * (kTR * kCPR) + li * kCPR;
 #pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) {
-            const uint4* rh = smem + buf * kImg + sub * (kTR * kCPR) + li * kCPR;
+        for (int s = 0; s < kNS; ++s) af[s] = rh[(2 * s + h) ^ (li & 15)];
+        const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kQT * kTR / 4);
 #pragma unroll
-            for (int s = 0; s < kNS; ++s) af[sub][s] = rh[(2 * s + h) ^ (li & 15)];
-        }
+        for (int ct = 0; ct < kQT; ++ct) {
 #pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) {
-            const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kQT * kTR / 4);
-#pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 z = tnl[ct * (kTR / 4) + 2 * g + h];      // rows 8g + 4h .. +3
-                    acc[sub][ct][4 * g + 0] = z.x; acc[sub][ct][4 * g + 1] = z.y; acc[sub][ct][4 * g + 2] = z.z; acc[sub][ct][4 * g + 3] = z.w;
-                }
+            for (int g = 0; g < 4; ++g) {
+                const float4 z = tnl[ct * (kTR / 4) + 2 * g + h];      // rows 8g + 4h .. +3
+                acc[ct][4 * g + 0] = z.x; acc[ct][4 * g + 1] = z.y; acc[ct][4 * g + 2] = z.z; acc[ct][4 * g + 3] = z.w;
             }
         }
 #pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) {
+        for (int s = 0; s < kNS; ++s) {
 #pragma unroll
-            for (int s = 0; s < kNS; ++s) {
-#pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) acc[sub][ct] = mfma_f16(af[sub][s], bh[ct][s], acc[sub][ct]);
-            }
+            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[s], bh[ct][s], acc[ct]);
         }
     };
 
@@ -368,17 +362,18 @@ __global__ __launch_bounds__(WAVES * 64, kBlocksPerCU) void l2_filter_kernel(
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (it + kDepth < n_iter) stage(tile_of(it + kDepth), nxt);
-        f32x16 acc[kSub][kQT];
-        tile_scores(cur, acc);
-        wait_ahead(min(kDepth, n_iter - 1 - it) - 1 < 0 ? 0 : min(kDepth, n_iter - 1 - it) - 1);   // tile it+1 landed
 #pragma unroll
         for (int sub = 0; sub < kSub; ++sub) {
+            f32x16 acc[kQT];
+            tile_scores(cur, sub, acc);
+            // tile it+1 landed (waited for before the first list store of this iteration is issued: the counter retires in order)
+            if (sub == 0) wait_ahead(min(kDepth, n_iter - 1 - it) - 1 < 0 ? 0 : min(kDepth, n_iter - 1 - it) - 1);
             if (priming) {
 #pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) prime(acc[sub][ct], ct);
+                for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
             } else {
 #pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) filter(acc[sub][ct], ct, t0 + sub * kTR);
+                for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0 + sub * kTR);
             }
         }
         if (it + 1 == n_prime) {
