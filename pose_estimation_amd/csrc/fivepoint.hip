@@ -91,7 +91,9 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
 // Stage 2: one lane per (sample, root): 6 samples x 10 roots per wave (lanes 60-63 idle).  The ten lanes
 // of a sample run the Aberth-Ehrlich iteration together (simultaneous update, roots exchanged by
 // shuffles), then every lane turns its own root into an essential matrix and writes slot k.
-__global__ __launch_bounds__(64) void fivepoint_roots_kernel(const ph5::Poly5* __restrict__ polys, long n_samples,
+// Three waves per SIMD (168 VGPR, 7 spilled, against 192): the 2 187 one-wave blocks of 32 pairs x 410 samples then run as
+// ONE round (256 CUs x 12 waves) instead of a full round and a tail, and a wave fits beside two waves of the L2 filter.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void fivepoint_roots_kernel(const ph5::Poly5* __restrict__ polys, long n_samples,
                                                             float* __restrict__ E_out, int32_t* __restrict__ n_sol) {
     const int lane = threadIdx.x;
     const int g = lane / 10, k = lane - 10 * g;
