@@ -2,85 +2,51 @@
 """bench.py — image pairs/s of the two-view relative-pose hot path on MI355X.
 
 Workload (BASELINE.json configs[1]): synthetic two-view pairs, 8192 SIFT-style float32
-descriptors (dim 128) per view, 4096 RANSAC essential-matrix hypotheses per pair.  One step =
+descriptors (dim 128) per view, >= 4096 RANSAC essential-matrix hypotheses (REAL models: a 5-point
+minimal sample yields ~4.6 real roots, so 920 samples = 9200 hypothesis slots) per pair.  One step =
 one pass of the hot path over a batch of --pairs such pairs per GPU, inputs resident in HBM:
 
     row norms -> L2 top-2 (fp16 MFMA candidate filter + exact f32 re-rank) -> ratio test -> compaction -> Philox minimal samples ->
-    5-point solver (hypothesis generation) -> Sampson scoring of H hypotheses -> best -> inlier mask ->
+    5-point solver (hypothesis generation) -> Sampson scoring of the hypotheses (bail-out) -> best -> inlier mask ->
     decomposition of the winning E (closed form on the device; --decompose host = NumPy SVD) -> 4-candidate
-    triangulation + cheirality vote -> pose table  (-> all_gather of the table when N > 1)
+    triangulation + cheirality vote -> pose table row -> LM refinement of the winning pose on the truncated Sampson cost
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
-torch.distributed.run, one rank per GPU; prints ONE JSON line on rank 0.
+Every step's [pairs,16] pose table lands in a [steps*pairs,16] buffer; when N > 1 there is ONE collective,
+an all_gather_into_tensor of that buffer after the last step, inside the timed region (north_star: final gather only).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 either launched under
+torch.distributed.run (one rank per GPU, env RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*), or — when WORLD_SIZE is not
+set — this script starts the N ranks itself as a child torch.distributed.run before touching the GPU and relays
+rank 0's line.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from pose_estimation_amd import matching, pipeline, synthetic  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 1024 SIMDs x 32768 FLOP / 32 cyc x 2.4 GHz
-L2_CALL_HBM_BYTES_AT_32_PAIRS = 816.0e6   # (1.1 + 66.3 + 100.0 + 168.8) MB FETCH_SIZE x 2 + (2.1 + 67.6 + 71.3 + 3.2) MB WRITE_SIZE
+# HBM bytes of l2_filter_kernel alone at 32 pairs, rocprofv3 --pmc offline (profiles/r2/, FETCH_SIZE x 2 + WRITE_SIZE)
+FILTER_HBM_BYTES_AT_32_PAIRS = None   # filled in from profiles/r2 once measured; None = not measured for this build
 N_FEAT, DIM = 8192, 128
-N_SAMPLES = 410                 # minimal samples per pair; the 5-point solver fills 10 hypothesis slots each
-N_HYP = 10 * N_SAMPLES          # 4100 essential-matrix hypotheses scored per pair (>= the 4096 of configs[1])
+N_SAMPLES = 920                 # minimal samples per pair; ~4.6 real essential matrices each => >= 4096 real hypotheses
 THR_PX = 1.0
 
 
-def make_batch(pairs, rank, dev):
-    d1, d2, k1, k2, truth = [], [], [], [], []
-    for p in range(pairs):
-        sc = synthetic.two_view_pair(n=N_FEAT, dim=DIM, seed=1002 + 7919 * rank + p)
-        d1.append(sc["desc1"]); d2.append(sc["desc2"]); k1.append(sc["kp1"]); k2.append(sc["kp2"])
-        truth.append((sc["R"], sc["t"]))
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev)
-    return dict(desc_q=t(d1), desc_t=t(d2), kp_q=t(k1), kp_t=t(k2), truth=truth,
-                host=dict(desc_q=d1, desc_t=d2, kp_q=k1, kp_t=k2))
-
-
-def cpu_baseline(batch, n_pairs, threads, E_dev):
-    """The CPU oracle ('port') over the same stages on a bounded sample of the same workload.
-
-    Hypothesis generation is NOT part of the CPU leg (the oracle's 5-point solver is NumPy and would
-    dominate it): the CPU scores the hypotheses the GPU generated, which only flatters the CPU."""
-    from oracle import oracle as orc
-    orc.set_num_threads(threads)
-    thr_sq = np.float32((THR_PX / synthetic.FX) ** 2)
-    h = dict(batch["host"], E=E_dev.cpu().numpy())
-    t0 = time.perf_counter()
-    for p in range(n_pairs):
-        idx, a, b = orc.match_l2_top2(h["desc_q"][p], h["desc_t"][p])
-        keep = orc.ratio_filter_l2(idx, a, b, 0.75)
-        m = orc.compact_matches(idx, keep, h["kp_q"][p], h["kp_t"][p])
-        n = m["n_match"]
-        pts = [m[k][:n] for k in ("x1", "y1", "x2", "y2")]
-        cnt = orc.score_essential(h["E"][p], *pts, thr_sq)
-        bi, _ = orc.select_best(cnt)
-        mask = orc.inlier_mask_essential(h["E"][p][bi], *pts, thr_sq, N_FEAT)
-        from pose_estimation_amd import geometry
-        P1, P2, _, _ = geometry.candidate_projections(h["E"][p][bi].reshape(1, 3, 3))
-        for c in range(4):
-            orc.triangulate(P1[0, c], P2[0, c], *pts, mask)
-    dt = time.perf_counter() - t0
-    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{n_pairs} pair(s) of the same workload through oracle/posehot_oracle.c (OpenMP, {threads} threads), hypothesis generation excluded, {dt:.1f} s"}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="pairs per step per GPU")
+    ap.add_argument("--samples", type=int, default=N_SAMPLES, help="5-point minimal samples per pair (10 hypothesis slots each)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs timed through the CPU oracle (0 = skip)")
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
@@ -91,15 +57,140 @@ def main():
     ap.add_argument("--decompose", default="device", choices=["device", "host"],
                     help="where the winning E is decomposed into its (R, t) candidates: closed form on the device "
                          "(no host round trip) or NumPy SVD on the host")
+    ap.add_argument("--no-refine", action="store_true", help="skip the LM refinement of the winning pose")
     ap.add_argument("--h2d", action="store_true",
                     help="PCIe-inclusive variant (never the headline): every step first copies its batch (descriptors + "
                          "keypoints) from pinned host memory into a per-stream device buffer on the step's stream")
-    ap.add_argument("--check", action="store_true", help="verify pose accuracy of the last step against ground truth")
-    args = ap.parse_args()
+    ap.add_argument("--sustained-s", type=float, default=2.0,
+                    help="seconds of back-to-back steps measured AFTER the timed region for the `sustained` key (0 = skip)")
+    ap.add_argument("--check", action="store_true", help="print pose accuracy of the last step against ground truth (stderr)")
+    return ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as a child
+    torch.distributed.run BEFORE this process touches the GPU, relay rank 0's JSON line, exit with the child's code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout.splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+        else:
+            print(line, file=sys.stderr)
+    raise SystemExit(proc.returncode)
+
+
+class HipEvents:
+    """Raw hipEvent_t pairs for ph_match_l2_top2_timed: the events are recorded by the library on the stream the
+    dominant kernel is launched on (torch.cuda.Event only ever sees torch's current stream and cannot reach inside a call)."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def pair(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        for e in (a, b):
+            rc = self.hip.hipEventCreate(ctypes.byref(e))
+            if rc != 0:
+                raise RuntimeError(f"hipEventCreate failed ({rc})")
+        return a, b
+
+    def elapsed_ms(self, pair):
+        ms = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), pair[0], pair[1])
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed ({rc})")
+        return float(ms.value)
+
+
+def make_batch(pairs, rank, dev):
+    import numpy as np
+    import torch
+    from pose_estimation_amd import synthetic
+    d1, d2, k1, k2, truth = [], [], [], [], []
+    for p in range(pairs):
+        sc = synthetic.two_view_pair(n=N_FEAT, dim=DIM, seed=1002 + 7919 * rank + p)
+        d1.append(sc["desc1"]); d2.append(sc["desc2"]); k1.append(sc["kp1"]); k2.append(sc["kp2"])
+        truth.append((sc["R"], sc["t"]))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.stack(a))).to(dev)
+    return dict(desc_q=t(d1), desc_t=t(d2), kp_q=t(k1), kp_t=t(k2), truth=truth,
+                host=dict(desc_q=d1, desc_t=d2, kp_q=k1, kp_t=k2))
+
+
+def cpu_baseline(batch, n_pairs, threads, E_dev, real_models):
+    """The CPU oracle ('port') over the same stages on a bounded sample of the same workload, and — beside it, as a
+    second stated figure — the matcher alone as NumPy/OpenBLAS sgemm + top-2 (what a SIMD BFMatcher roughly costs).
+
+    Hypothesis generation is NOT part of the CPU leg (the oracle's 5-point solver is NumPy and would
+    dominate it): the CPU scores the hypotheses the GPU generated, which only flatters the CPU."""
+    import numpy as np
+    from oracle import oracle as orc
+    from pose_estimation_amd import geometry, synthetic
+    orc.set_num_threads(threads)
+    thr_sq = np.float32((THR_PX / synthetic.FX) ** 2)
+    h = dict(batch["host"], E=E_dev.cpu().numpy())
+    t0 = time.perf_counter()
+    t_match = 0.0
+    for p in range(n_pairs):
+        tm = time.perf_counter()
+        idx, a, b = orc.match_l2_top2(h["desc_q"][p], h["desc_t"][p])
+        t_match += time.perf_counter() - tm
+        keep = orc.ratio_filter_l2(idx, a, b, 0.75)
+        m = orc.compact_matches(idx, keep, h["kp_q"][p], h["kp_t"][p])
+        n = m["n_match"]
+        pts = [m[k][:n] for k in ("x1", "y1", "x2", "y2")]
+        cnt = orc.score_essential(h["E"][p], *pts, thr_sq)
+        bi, _ = orc.select_best(cnt)
+        mask = orc.inlier_mask_essential(h["E"][p][bi], *pts, thr_sq, N_FEAT)
+        P1, P2, _, _ = geometry.candidate_projections(h["E"][p][bi].reshape(1, 3, 3))
+        for c in range(4):
+            orc.triangulate(P1[0, c], P2[0, c], *pts, mask)
+    dt = time.perf_counter() - t0
+    # second figure: BLAS matcher (not bit-exact with the contract; a fairer stand-in for OpenCV's SIMD BFMatcher)
+    tb = time.perf_counter()
+    nb = min(n_pairs, 8)
+    for p in range(nb):
+        q, t = h["desc_q"][p], h["desc_t"][p]
+        s = q @ t.T
+        s -= 0.5 * np.einsum("ij,ij->i", t, t)[None, :]
+        top = np.argpartition(-s, 2, axis=1)[:, :2]
+        _ = np.take_along_axis(s, top, axis=1)
+    blas_dt = (time.perf_counter() - tb) / nb
+    rest = (dt - t_match) / n_pairs
+    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n_pairs} pair(s) of the same workload through oracle/posehot_oracle.c (OpenMP, {threads} threads), "
+                      f"exhaustive scoring of the {E_dev.shape[1]} hypothesis slots the GPU generated (~{real_models:.0f} real models), "
+                      f"hypothesis generation excluded, {dt:.1f} s",
+            "blas_matcher": {"value": 1.0 / (blas_dt + rest), "unit": "pairs/s",
+                             "note": "same CPU leg with the matcher replaced by NumPy/OpenBLAS sgemm q@t.T + argpartition top-2 "
+                                     f"({blas_dt * 1e3:.0f} ms per pair over {nb} pairs; NOT bit-exact with the contract's fma chain), "
+                                     "the rest of the stages as in `value`"}}
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)                                  # never returns
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import numpy as np
+    import torch
+    from pose_estimation_amd import matching, pipeline, synthetic
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local)
@@ -110,6 +201,7 @@ def main():
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
         sys.stdout.flush()
         saved = os.dup(1)
@@ -123,12 +215,15 @@ def main():
             os.dup2(saved, 1)
             os.close(saved)
 
-    P = args.pairs
+    P, S = args.pairs, args.samples
     batch = make_batch(P, rank, dev)
     thr_sq = float(np.float32((THR_PX / synthetic.FX) ** 2))
-    gathered = torch.empty((world * P, 16), dtype=torch.float32, device=dev) if use_dist else None
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    state = {"step": -1}
+    tables = torch.zeros((args.steps * P, 16), dtype=torch.float32, device=dev)            # this rank's rows, step after step
+    gathered = torch.empty((world * args.steps * P, 16), dtype=torch.float32, device=dev) if use_dist else None
+    hev = HipEvents()
+    kev = [hev.pair() for _ in range(args.steps)]          # around the dominant kernel of every timed step
+    state = {"step": -1, "timed": False}
+    counts = []                                            # per-step [P, S] numbers of real models (summed after the region)
 
     keys = ("desc_q", "desc_t", "kp_q", "kp_t")
     pinned = {k: batch[k].cpu().pin_memory() for k in keys} if args.h2d else None
@@ -140,11 +235,8 @@ def main():
         nq = matching.row_sqnorm(b["desc_q"])
         nt = matching.row_sqnorm(b["desc_t"])
         k = state["step"]
-        if k >= 0:
-            ev[k][0].record()
-        r = matching.match_l2(b["desc_q"], b["desc_t"], norm_q=nq, norm_t=nt, precision=args.precision)
-        if k >= 0:
-            ev[k][1].record()
+        r = matching.match_l2(b["desc_q"], b["desc_t"], norm_q=nq, norm_t=nt, precision=args.precision,
+                              kernel_events=kev[k] if state["timed"] else None)
         return (*r, "l2")
 
     def front(slot=0):
@@ -154,36 +246,45 @@ def main():
                 cur["buf"][k].copy_(pinned[k], non_blocking=True)
         b = cur["buf"]
         return pipeline.relative_pose_front(match, b["kp_q"], b["kp_t"], None, None, None, thr_sq,
-                                            n_samples=N_SAMPLES, seed=max(state["step"], 0) + 1000,
-                                            decompose=args.decompose)
+                                            n_samples=S, seed=max(state["step"], 0) + 1000,
+                                            decompose=args.decompose, want_counts=True, refine=not args.no_refine)
 
-    def back(f):
+    def back(f, k, timed):
         out = pipeline.relative_pose_back(f)
-        if use_dist:
-            dist.all_gather_into_tensor(gathered, out["table"])
+        if timed:
+            tables[k * P:(k + 1) * P].copy_(out["table"], non_blocking=True)
+            counts.append(out["n_solutions"])
         return out
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream()]
+    main_stream = torch.cuda.current_stream()
     for st in streams:
-        st.wait_stream(torch.cuda.current_stream())
+        st.wait_stream(main_stream)
 
-    def run(n_steps, timed):
-        """n_steps whole batches.  The front half of batch k+1 is enqueued before the host finishes batch k
-        (its 3x3 SVDs), so the GPU does not idle during the host round trip; every batch is completed
-        (pose table written, gathered) inside the call.  Batch k lives on stream k mod --streams."""
+    def run(n_steps, timed, gather=False):
+        """n_steps whole batches.  The front half of batch k+1 is enqueued before the back half of batch k (with
+        --decompose host the back half waits for a host round trip), every batch is completed (pose table row block
+        written) inside the call.  Batch k lives on stream k mod --streams.  gather: after the last batch, the ONE
+        collective of the job, on the main stream once every batch stream has been waited for."""
         pending, out = None, None
+        state["timed"] = timed
         for k in range(n_steps):
-            state["step"] = k if timed else -1
+            state["step"] = k
             st = streams[k % len(streams)]
             with torch.cuda.stream(st):
                 f = front(k % len(streams))
             if pending is not None:
                 with torch.cuda.stream(pending[1]):
-                    out = back(pending[0])
-            pending = (f, st)
+                    out = back(pending[0], pending[2], timed)
+            pending = (f, st, k)
         if pending is not None:
             with torch.cuda.stream(pending[1]):
-                out = back(pending[0])
+                out = back(pending[0], pending[2], timed)
+        if gather and use_dist:
+            for st in streams:
+                main_stream.wait_stream(st)
+            dist.all_gather_into_tensor(gathered, tables)
+        state["timed"] = False
         return out
 
     def barrier():
@@ -194,30 +295,79 @@ def main():
     run(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    out = run(args.steps, True)
+    out = run(args.steps, True, gather=True)
     barrier()
     dt = time.perf_counter() - t0
-    state["step"] = -1
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # ---- what the timed region computed: real hypotheses per pair, matches per pair, the gathered table
+    real_per_pair = float(torch.stack([c.sum(dim=1).float().mean() for c in counts]).mean().item())
+    matches_per_pair = float(tables[:, 13].mean().item())
+    inliers_per_pair = float(tables[:, 12].mean().item())
+    if use_dist:
+        stats = torch.tensor([real_per_pair, matches_per_pair, inliers_per_pair], dtype=torch.float64, device=dev)
+        dist.all_reduce(stats)
+        real_per_pair, matches_per_pair, inliers_per_pair = (stats / world).tolist()
+        mine = gathered[rank * args.steps * P:(rank + 1) * args.steps * P]
+        if not torch.equal(mine, tables):
+            raise SystemExit("gathered pose table does not hold this rank's rows")
+    if not bool((tables[:, 15] == pipeline.STATUS_OK).all()):
+        raise SystemExit("a timed step left a pose-table row without STATUS_OK")
+
+    # ---- sustained rate: back-to-back steps for >= --sustained-s seconds after the timed region (same code path)
+    sustained = None
+    if args.sustained_s > 0:
+        n_sus = max(args.steps, int(args.sustained_s / (dt / args.steps)) + 1)
+        barrier()
+        ts = time.perf_counter()
+        run(n_sus, False)
+        barrier()
+        sus_dt = time.perf_counter() - ts
+        if use_dist:
+            tmax = torch.tensor([sus_dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sus_dt = float(tmax.item())
+        sustained = {"value": world * P * n_sus / sus_dt, "unit": "pairs/s", "steps": n_sus, "seconds": sus_dt}
+
+    # ---- roofline of the dominant kernel.  frac = the kernel ALONE on the device (events recorded by the library around
+    # the kernel, one stream, nothing else in flight): the number a rocprofv3 --kernel-trace of `bench.py --streams 1`
+    # reproduces.  The brackets of the timed region (other streams' kernels share the CUs then) are kept as contended_*.
     flops = 2.0 * N_FEAT * N_FEAT * DIM * P
-    achieved = flops / (kern_ms * 1e-3) / 1e12
-    # the same matcher call alone on the device (no other stream's kernels beside it): 5 launches after the timed region
+    contended_us = float(np.mean([hev.elapsed_ms(p) for p in kev])) * 1e3
     nq_, nt_ = matching.row_sqnorm(batch["desc_q"]), matching.row_sqnorm(batch["desc_t"])
-    iso = []
-    for _ in range(5):
+    iso_k, iso_call = [], []
+    for _ in range(6):
+        pr = hev.pair()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
-        matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq_, norm_t=nt_, precision=args.precision)
+        matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq_, norm_t=nt_, precision=args.precision, kernel_events=pr)
         b.record()
         torch.cuda.synchronize()
-        iso.append(a.elapsed_time(b))
-    iso_ms = float(np.mean(iso[1:]))
+        iso_k.append(hev.elapsed_ms(pr) * 1e3)
+        iso_call.append(a.elapsed_time(b) * 1e3)
+    kern_us, call_us = float(np.mean(iso_k[1:])), float(np.mean(iso_call[1:]))
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else PEAK_F16_MFMA_TFLOPS
+    achieved = flops / (kern_us * 1e-6) / 1e12
+    roofline = {
+        "kernel": "l2_top2_f32_kernel<128>" if args.precision == 0 else "l2_filter_kernel<4>",
+        "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+        "traffic": (FILTER_HBM_BYTES_AT_32_PAIRS * P / 32) if (args.precision == 1 and FILTER_HBM_BYTES_AT_32_PAIRS) else None,
+        "dominant_kernel_us": kern_us,
+        "how": "HIP events recorded by ph_match_l2_top2_timed around the kernel alone, on its stream, mean of 5 launches "
+               "with nothing else in flight; reproduce: rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1",
+        "algorithmic_flops_per_launch": flops,
+        "executed_mfma_flops_per_launch": flops * (1 + 8 / 256) if args.precision == 1 else flops,
+        "contended_kernel_us": contended_us, "contended_frac": flops / (contended_us * 1e-6) / 1e12 / peak,
+        "contended_note": f"the same kernel inside the timed region, {args.streams} stream(s): other batches' kernels share the CUs",
+        "matcher_call_us": call_us, "matcher_call_frac": flops / (call_us * 1e-6) / 1e12 / peak,
+        "matcher_call": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel"
+                        if args.precision == 1 else "ph_match_l2_top2 = l2_top2_f32_kernel<128>",
+        "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+        "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0)"}
 
     if args.check and rank == 0:
         from pose_estimation_amd import geometry
@@ -228,50 +378,39 @@ def main():
             print(f"# pair {p}: matches {int(tab[p,13])} inliers {int(tab[p,12])} rot err {ra:.4f} deg, t dir err {ta:.4f} deg",
                   file=sys.stderr)
 
-    if args.precision == 0:
-        roofline = {"kernel": "l2_top2_f32_kernel<128>", "bound": "mfma", "achieved": achieved,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": None, "launch_ms": kern_ms, "algorithmic_flops_per_launch": flops}
-    else:
-        # One ph_match_l2_top2 call = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel; the
-        # events bracket the call on its own stream.  `achieved` counts the ALGORITHMIC 2*N*M*D flops per pair; the filter
-        # executes one fp16 MFMA product per algorithmic product (+3 % priming).  With --streams > 1 other batches' kernels
-        # share the device during the call, so launch_ms is the duration under that contention; isolated_launch_ms is the
-        # same call alone.
-        roofline = {"kernel": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel",
-                    "bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F16_MFMA_TFLOPS,
-                    # HBM bytes per launch, rocprofv3 --pmc offline (profiles/r1/l2_filter_f16_v9_traffic_pmc_summary.json): FETCH_SIZE x2
-                    # (gfx950 correction) + WRITE_SIZE over the four kernels of the call at 32 pairs; scaled by pairs
-                    "traffic": L2_CALL_HBM_BYTES_AT_32_PAIRS * P / 32, "launch_ms": kern_ms, "isolated_launch_ms": iso_ms,
-                    "isolated_achieved": flops / (iso_ms * 1e-3) / 1e12,
-                    "isolated_frac": flops / (iso_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                    "algorithmic_flops_per_launch": flops, "executed_f16_mfma_flops_per_launch": flops * (1 + 8 / 256),
-                    "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                    "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0, 81 % of the f32 MFMA peak)"}
     if rank == 0:
+        pairs_s = world * P * args.steps / dt
         res = {
-            "metric": "image pairs/sec (relative pose, whole node) at 8k feats",
-            "value": world * P * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": "image pairs/sec (relative pose, whole node) at 8k feats; RANSAC hyps/sec",
+            "value": pairs_s, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "l2_precision": args.precision,
+            "vs_baseline": None,
+            "dtype": "f32 (outputs bit-exact f32; contraction on fp16 MFMA + exact f32 re-rank)" if args.precision == 1 else "f32",
+            "data": "synthetic", "l2_precision": args.precision,
             "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
-                                   "4096 essential-matrix hypotheses per pair", "pairs_per_step_per_gpu": P,
-                       "features": N_FEAT, "dim": DIM, "hypotheses": N_HYP, "ratio": 0.75, "threshold_px": THR_PX,
-                       "minimal_samples": N_SAMPLES, "streams": args.streams, "decompose": args.decompose,
+                                   ">= 4096 essential-matrix hypotheses (real models) per pair", "pairs_per_step_per_gpu": P,
+                       "features": N_FEAT, "dim": DIM, "hypotheses": real_per_pair, "hypothesis_slots": 10 * S,
+                       "minimal_samples": S, "ratio": 0.75, "threshold_px": THR_PX, "scoring": "bail-out",
+                       "refine": "none" if args.no_refine else f"device LM, {pipeline.REFINE_ITERS} iterations, Sampson cost truncated at {pipeline.REFINE_TRUNC:g} x threshold",
+                       "streams": args.streams, "decompose": args.decompose,
                        "inputs": "pinned host memory, copied over PCIe inside every step (NOT the headline)" if args.h2d else "resident in HBM",
-                       "hypothesis_source": "generated in the timed region: Philox minimal samples of the pair's own matches -> device 5-point solver (10 slots per sample)",
-                       "parallelism": f"pairs sharded over {world} rank(s), final all_gather of the [pairs,16] pose table"},
-            "hyps_per_sec": world * P * N_HYP * args.steps / dt,
+                       "hypothesis_source": "generated in the timed region: Philox minimal samples of the pair's own matches -> device 5-point solver "
+                                            "(10 slots per sample; `hypotheses` = mean number of REAL models per pair = sum of n_solutions)",
+                       "parallelism": f"pairs sharded over {world} rank(s), ONE all_gather of the [steps*pairs,16] pose table after the last step"},
+            "hyps_per_sec": pairs_s * real_per_pair, "hyps_per_sec_counts": "real models generated + scored (bail-out) per second; "
+                            "exhaustive scoring alone: benchmarks/kernels.py, profiles/r2/kernels_*.jsonl",
+            "matches_per_pair": matches_per_pair, "inliers_per_pair": inliers_per_pair,
+            "sustained": sustained,
             "roofline": roofline,
         }
+        if real_per_pair < 4096:
+            res["config"]["warning"] = f"only {real_per_pair:.0f} real hypotheses per pair: raise --samples"
         if world == 1 and args.cpu_pairs > 0:
             threads = min(16, os.cpu_count() or 1)
-            res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads, out["E_hyp"])
-        print(json.dumps(res))
+            res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads, out["E_hyp"], real_per_pair)
+        print(json.dumps(res), flush=True)
     if use_dist:
-        if rank == 0 and not torch.equal(gathered[:P], out["table"]):
-            raise SystemExit("gathered pose table does not hold this rank's rows")
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -20,6 +20,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pose_estimation_amd import geometry, matching, pipeline, sharding, synthetic  # noqa: E402
+from pose_estimation_amd.allpairs import AllPairs  # noqa: E402
 
 
 def cfg5(args, dev):
@@ -73,6 +74,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--f32", action="store_true", help="cfg 3/4 with float32 x 128 descriptors and the L2 matcher")
     ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--no-refine", action="store_true", help="report the winning minimal-sample model as it is")
     args = ap.parse_args()
     if args.cfg == 5:
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -83,6 +85,19 @@ def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)                       # RCCL's banner goes to stderr: stdout carries the ONE JSON line of rank 0
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     t0 = time.perf_counter()
     if args.f32:
@@ -90,57 +105,69 @@ def main():
     else:
         sc = synthetic.binary_views(V, n, seed=1000 + args.cfg, config=args.cfg)
     gen_s = time.perf_counter() - t0
-    print(f"# scene generated in {gen_s:.1f} s", file=sys.stderr, flush=True)
+    print(f"# rank {rank}: scene generated in {gen_s:.1f} s", file=sys.stderr, flush=True)
     desc = torch.from_numpy(sc["desc"]).to(dev)
     kp = torch.from_numpy(sc["kp"]).to(dev)
     norms = matching.row_sqnorm(desc) if args.f32 else None
     vi, vj = synthetic.all_pairs(V)
     if args.pairs:
         vi, vj = vi[:args.pairs], vj[:args.pairs]
-    mine = sharding.shard_indices(len(vi), rank, world).numpy()         # block-cyclic shard of the pair list
-    vi, vj = vi[mine], vj[mine]
     thr_sq = float(np.float32((1.5 / synthetic.FX) ** 2))
-    vi_d, vj_d = torch.from_numpy(vi).to(dev), torch.from_numpy(vj).to(dev)
+    run = AllPairs(desc, kp, norms, thr_sq, args.samples, args.f32, refine=not args.no_refine)
 
-    def chunk(s, e):
-        q, t = vi_d[s:e], vj_d[s:e]
-        if args.f32:
-            match = lambda: (*matching.match_l2(desc, desc, q, t, norm_q=norms, norm_t=norms), "l2")
-        else:
-            match = lambda: (*matching.match_hamming(desc, desc, q, t), "hamming")
-        return pipeline.relative_pose_batch(match, kp, kp, q, t, None, thr_sq, ratio=0.8, n_samples=args.samples,
-                                            seed=s)["table"]
-
-    chunk(0, min(args.chunk, len(vi)))                  # warm-up chunk (also the first real chunk's shapes)
+    # warm-up chunk (also the first real chunk's shapes), outside the timed region
+    w = min(args.chunk, len(vi))
+    run.chunk(0, torch.arange(w), vi[:w], vj[:w]); run.real_models.zero_()
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
-    tables = []
-    t0 = time.perf_counter()
-    for k, s in enumerate(range(0, len(vi), args.chunk)):
-        with torch.cuda.stream(streams[k % len(streams)]):
-            tables.append(chunk(s, min(s + args.chunk, len(vi))))
+
+    def progress(k, done):
         if k % 256 == 255:
-            print(f"# {s + args.chunk} pairs enqueued", file=sys.stderr, flush=True)
+            print(f"# rank {rank}: {done} pairs enqueued", file=sys.stderr, flush=True)
+
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
-    table = torch.cat(tables)
+    t0 = time.perf_counter()
+    # shard (pair_id % world), chunks alternating over the streams, ONE all_gather of the pose table at the end
+    full, local, mine = sharding.run_pair_list(vi, vj, run.chunk, rank, world, chunk=args.chunk,
+                                               stream_ctx=lambda k: torch.cuda.stream(streams[k % len(streams)]),
+                                               sync=torch.cuda.synchronize, progress=progress, device=dev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-
-    tab = table.cpu().numpy()
-    rerr, terr = [], []
-    for p in range(len(vi)):
-        R, t = synthetic.relative_pose(sc["R"][vi[p]], sc["t"][vi[p]], sc["R"][vj[p]], sc["t"][vj[p]])
-        rerr.append(geometry.rotation_angle_deg(tab[p, :9].reshape(3, 3), R))
-        terr.append(geometry.direction_angle_deg(tab[p, 9:12], t))
-    rerr, terr = np.array(rerr), np.array(terr)
-    print(json.dumps({"cfg": args.cfg, "descriptors": "f32x128" if args.f32 else "256-bit", "streams": args.streams,
-                      "views": V, "features": n, "pairs": int(len(vi)), "rank": rank, "world": world,
-                      "seconds": dt, "pairs_per_s": len(vi) / dt, "hyps_per_s": len(vi) * 10 * args.samples / dt,
-                      "scene_generation_s": gen_s, "median_matches": float(np.median(tab[:, 13])),
-                      "median_inliers": float(np.median(tab[:, 12])),
-                      "rot_err_deg": {"median": float(np.median(rerr)), "p95": float(np.percentile(rerr, 95)), "max": float(rerr.max())},
-                      "t_dir_err_deg": {"median": float(np.median(terr)), "p95": float(np.percentile(terr, 95)), "max": float(terr.max())},
-                      "ok_within_1deg": float(np.mean((rerr < 1.0) & (terr < 1.0)))}))
+    real = run.real_models.clone()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(real)
+        dt = float(tmax.item())
+    line = {"cfg": args.cfg, "descriptors": "f32x128" if args.f32 else "256-bit", "streams": args.streams,
+            "views": V, "features": n, "pairs": int(len(vi)), "pairs_this_rank": int(len(mine)), "rank": rank, "world": world,
+            "seconds": dt, "pairs_per_s": len(vi) / dt,
+            "minimal_samples": args.samples, "hypothesis_slots": 10 * args.samples,
+            "hypotheses": float(real.item()) / len(vi), "hyps_per_s": float(real.item()) / dt, "scoring": "bail-out",
+            "refine": "device LM on the Sampson error over the inliers" if not args.no_refine else "none",
+            "gather": "one all_gather_into_tensor of the [pairs,16] pose table after the last chunk, inside the timed region",
+            "scene_generation_s": gen_s}
+    if rank != 0:
+        print("# " + json.dumps({k: line[k] for k in ("rank", "pairs_this_rank", "seconds")}), file=sys.stderr, flush=True)
+    else:
+        tab = full.cpu().numpy()
+        assert tab.shape[0] == len(vi)
+        rerr, terr = [], []
+        for p in range(len(vi)):
+            R, t = synthetic.relative_pose(sc["R"][vi[p]], sc["t"][vi[p]], sc["R"][vj[p]], sc["t"][vj[p]])
+            rerr.append(geometry.rotation_angle_deg(tab[p, :9].reshape(3, 3), R))
+            terr.append(geometry.direction_angle_deg(tab[p, 9:12], t))
+        rerr, terr = np.array(rerr), np.array(terr)
+        line.update({"median_matches": float(np.median(tab[:, 13])), "median_inliers": float(np.median(tab[:, 12])),
+                     "rot_err_deg": {"median": float(np.median(rerr)), "p95": float(np.percentile(rerr, 95)), "max": float(rerr.max())},
+                     "t_dir_err_deg": {"median": float(np.median(terr)), "p95": float(np.percentile(terr, 95)), "max": float(terr.max())},
+                     "ok_within_1deg": float(np.mean((rerr < 1.0) & (terr < 1.0)))})
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

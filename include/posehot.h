@@ -92,6 +92,18 @@ int ph_match_l2_top2(const float* desc_q, const float* desc_t,
                      int32_t* idx, float* d1sq, float* d2sq,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement hook (no reference counterpart; bench.py's roofline object): ph_match_l2_top2 with two caller-created
+ * hipEvent_t (as void*, either may be NULL) recorded on `stream` immediately before and after the call's DOMINANT
+ * kernel alone — l2_filter_kernel for PH_PRECISION_F16_RERANK, l2_top2_f32_kernel for PH_PRECISION_F32 — so its
+ * duration can be read with hipEventElapsedTime while the call runs inside a whole step. */
+int ph_match_l2_top2_timed(const float* desc_q, const float* desc_t,
+                           const float* norm_q, const float* norm_t,
+                           const int32_t* view_q, const int32_t* view_t,
+                           const int32_t* n_q, const int32_t* n_t,
+                           int B, int nq, int nt, int dim, int precision,
+                           int32_t* idx, float* d1sq, float* d2sq,
+                           void* ws, size_t ws_bytes, void* stream, void* ev_begin, void* ev_end);
+
 /* Lowe ratio test, strict '<':  keep[i] = idx[i] >= 0 && second exists && d1 < ratio * d2.
  * Hamming form compares d1 < ratio*d2 in f32; L2 form takes SQUARED distances and compares
  * d1sq < ratio^2 * d2sq (== d1 < ratio*d2 on true distances).  n = B*nq elements. */
@@ -127,6 +139,12 @@ int ph_compact_matches(const int32_t* idx, const int32_t* keep,
  * No reference counterpart (the reference has no RANSAC); SURVEY.md §7 "Counter-based RNG". */
 int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, int N, int S, int m,
                       int32_t* samples, void* stream);
+/* The same with the Philox key's second word taken from item_key[b] (device uint32 [B]; NULL = b) instead of the
+ * item's position in the batch: a pair keyed by its GLOBAL pair id draws the same samples whichever rank, chunk or
+ * batch slot it lands in, so a sharded run reproduces the unsharded one row for row (the pair loop
+ * being sharded is main.py:458-463).  No reference counterpart. */
+int ph_sample_minimal_keyed(uint32_t seed, const uint32_t* item_key, const int32_t* n_valid, int B, int N, int S,
+                            int m, int32_t* samples, void* stream);
 
 /* Nister 5-point essential-matrix solver (float64 inside).  Two launches: one thread per minimal
  * sample builds the degree-10 polynomial, then one lane per (sample, root) runs the Aberth-Ehrlich
@@ -232,6 +250,22 @@ int ph_decompose_essential(const float* E, const int32_t* sel, int B, int H,
 int ph_pose_table(const float* P2, const int32_t* front, int C,
                   const int32_t* best_count, const int32_t* n_match, const int32_t* best_idx,
                   int B, int min_inliers, float* table, int32_t* win, void* stream);
+
+/* Refinement of B relative poses on their correspondences (north_star: "the per-hypothesis refinement"; no
+ * reference counterpart — the reference's only refinement is the LM inside cv2.solvePnP, main.py:101-104, which
+ * ph_refine_pose_lm restates; this is its two-view analogue).  Levenberg-Marquardt, float64, one block per item, on
+ *     sum_i min(r_i^2, trunc_sq),   r_i = the signed Sampson distance of correspondence i under E = [t]x R,
+ * over the 5 degrees of freedom of (R, t), |t| = 1 (R <- exp([dw]x) R, t moved in its tangent plane).  A
+ * correspondence enters the normal equations of a pass iff r_i^2 < trunc_sq at that pass's pose (truncated
+ * quadratic / MSAC loss), so the inlier set follows the pose; `mask` ([B][ceil(N/64)], may be NULL) restricts the
+ * correspondences considered at all.  pose_rt: B rows of `stride` (>= 12) floats, R row-major (9) then t (3) —
+ * e.g. the pose table of ph_pose_table with stride 16 — refined IN PLACE (a row with a zero/non-finite t, fewer
+ * than 6 correspondences or max_iters == 0 stays bit for bit).  rms [B] f64 (may be NULL) = root mean square of r
+ * over the final inliers, n_inliers [B] their number, iters [B] the iterations run.  CPU twin: oracle/refine_e.py. */
+int ph_refine_relative_pose(const float* x1, const float* y1, const float* x2, const float* y2,
+                            const uint64_t* mask, const int32_t* n_valid, int B, int N, float trunc_sq,
+                            int max_iters, float* pose_rt, int stride, double* rms, int32_t* n_inliers,
+                            int32_t* iters, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (4) Board-pose helpers: the reference's own arithmetic, batched.

@@ -243,12 +243,12 @@ def rodrigues_inv(R):
     """Rotation matrix -> rotation vector (inverse of the above; angle in [0, pi])."""
     R = np.asarray(R, np.float64)
     c = np.clip((np.trace(R) - 1) / 2, -1, 1)
-    th = np.arccos(c)
     w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    th = np.arctan2(0.5 * np.linalg.norm(w), c)      # not arccos(c): its slope is 1/sin(theta) next to 0 and pi
     if th < 1e-10:
         return w / 2
     if np.pi - th < 1e-6:
-        A = (R + np.eye(3)) / 2
+        A = ((R + R.T) / 2 - c * np.eye(3)) / (1 - c)      # = k k' exactly: sym(R) = cos I + (1 - cos) k k'
         k = np.sqrt(np.maximum(np.diag(A), 0))
         i = int(np.argmax(k))
         k = A[i] / k[i]

@@ -41,15 +41,18 @@ SIGNATURES = {
     "ph_match_l2_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ph_row_sqnorm": (_i, [_p, _i64, _i, _p, _p]),
     "ph_match_l2_top2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "ph_match_l2_top2_timed": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p, _p, _p]),
     "ph_ratio_filter_hamming": (_i, [_p, _p, _p, _i64, _f, _p, _p]),
     "ph_ratio_filter_l2": (_i, [_p, _p, _p, _i64, _f, _p, _p]),
     "ph_compact_matches": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "ph_sample_minimal": (_i, [C.c_uint32, _p, _i, _i, _i, _i, _p, _p]),
+    "ph_sample_minimal_keyed": (_i, [C.c_uint32, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ph_solve_essential_5pt_ws_bytes": (_sz, [_i, _i]),
     "ph_solve_essential_5pt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
     "ph_gather_models": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "ph_decompose_essential": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ph_pose_table": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "ph_refine_relative_pose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _i, _p, _p, _p, _p]),
     "ph_solve_p3p": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "ph_score_essential": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p]),
     "ph_score_pnp": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p]),

@@ -201,12 +201,13 @@ def rodrigues(rvec):
 
 def rotation_to_rvec(R):
     R = np.asarray(R, np.float64)
-    th = np.arccos(np.clip((np.trace(R) - 1) / 2, -1, 1))
     w = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    th = np.arctan2(0.5 * np.linalg.norm(w), np.clip((np.trace(R) - 1) / 2, -1, 1))   # accurate next to 0 and pi, unlike arccos
     if th < 1e-10:
         return w / 2
     if np.pi - th < 1e-6:
-        A = (R + np.eye(3)) / 2
+        c = np.clip((np.trace(R) - 1) / 2, -1, 1)
+        A = ((R + R.T) / 2 - c * np.eye(3)) / (1 - c)      # = k k' exactly: sym(R) = cos I + (1 - cos) k k'
         d = np.sqrt(np.maximum(np.diag(A), 0))
         i = int(np.argmax(d))
         k = A[i] / d[i]

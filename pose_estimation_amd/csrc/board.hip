@@ -161,16 +161,19 @@ __device__ __forceinline__ void mat3_mul(const double (&A)[9], const double (&B)
 __device__ void log_so3(const double (&R)[9], double* w) {
     const double tr = R[0] + R[4] + R[8];
     const double c = fmin(fmax((tr - 1.0) * 0.5, -1.0), 1.0);
-    const double th = acos(c);
     const double a0 = R[7] - R[5], a1 = R[2] - R[6], a2 = R[3] - R[1];
+    const double th = atan2(0.5 * sqrt(a0 * a0 + a1 * a1 + a2 * a2), c);    // not acos(c): its slope is 1/sin(theta) next to 0 and pi
     if (th < 1e-10) { w[0] = 0.5 * a0; w[1] = 0.5 * a1; w[2] = 0.5 * a2; return; }
     if (3.141592653589793 - th < 1e-6) {
-        const double d0 = sqrt(fmax((R[0] + 1.0) * 0.5, 0.0)), d1 = sqrt(fmax((R[4] + 1.0) * 0.5, 0.0)),
-                     d2 = sqrt(fmax((R[8] + 1.0) * 0.5, 0.0));
+        // sym(R) = cos I + (1 - cos) k k'  ->  k k' = (sym(R) - c I) / (1 - c), exact for every angle
+        const double f = 1.0 / (1.0 - c);
+        const double d0 = sqrt(fmax((R[0] - c) * f, 0.0)), d1 = sqrt(fmax((R[4] - c) * f, 0.0)),
+                     d2 = sqrt(fmax((R[8] - c) * f, 0.0));
+        const double s01 = (R[1] + R[3]) * 0.5 * f, s02 = (R[2] + R[6]) * 0.5 * f, s12 = (R[5] + R[7]) * 0.5 * f;
         double k[3];
-        if (d0 >= d1 && d0 >= d2) { k[0] = d0; k[1] = (R[1] + R[3]) * 0.25 / d0; k[2] = (R[2] + R[6]) * 0.25 / d0; }
-        else if (d1 >= d2) { k[1] = d1; k[0] = (R[1] + R[3]) * 0.25 / d1; k[2] = (R[5] + R[7]) * 0.25 / d1; }
-        else { k[2] = d2; k[0] = (R[2] + R[6]) * 0.25 / d2; k[1] = (R[5] + R[7]) * 0.25 / d2; }
+        if (d0 >= d1 && d0 >= d2) { k[0] = d0; k[1] = s01 / d0; k[2] = s02 / d0; }
+        else if (d1 >= d2) { k[1] = d1; k[0] = s01 / d1; k[2] = s12 / d1; }
+        else { k[2] = d2; k[0] = s02 / d2; k[1] = s12 / d2; }
         const double sgn = (a0 * k[0] + a1 * k[1] + a2 * k[2]) < 0.0 ? -1.0 : 1.0;
         w[0] = sgn * th * k[0]; w[1] = sgn * th * k[1]; w[2] = sgn * th * k[2];
         return;

@@ -35,7 +35,8 @@ __device__ __forceinline__ uint32_t philox_word0(uint32_t c0, uint32_t c1, uint3
 
 // sample s of item b: m distinct indices in [0, n_valid[b]); draw t = Philox(counter (s,t,0,0), key (seed,b))
 // word 0 mapped by multiply-shift; a repeated index is skipped.  n_valid < m -> -1.
-__global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const int32_t* __restrict__ n_valid, int N, int S, int m,
+__global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const uint32_t* __restrict__ item_key,
+                                                    const int32_t* __restrict__ n_valid, int N, int S, int m,
                                                     int32_t* __restrict__ out) {
     const int b = blockIdx.y;
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -43,10 +44,11 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const int32_
     const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
     int32_t* o = out + ((size_t)b * S + s) * m;
     if (nv < m) { for (int k = 0; k < m; ++k) o[k] = -1; return; }
+    const uint32_t key = item_key ? item_key[b] : (uint32_t)b;
     int got[8];
     int n = 0;
     for (uint32_t t = 0; n < m; ++t) {
-        const uint32_t w = philox_word0((uint32_t)s, t, seed, (uint32_t)b);
+        const uint32_t w = philox_word0((uint32_t)s, t, seed, key);
         const int idx = (int)(((uint64_t)w * (uint64_t)nv) >> 32);
         bool dup = false;
         for (int k = 0; k < n; ++k) dup |= (got[k] == idx);
@@ -149,15 +151,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 
 }  // namespace
 
-extern "C" int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, int N, int S, int m, int32_t* samples,
-                                 void* stream) {
+extern "C" int ph_sample_minimal_keyed(uint32_t seed, const uint32_t* item_key, const int32_t* n_valid, int B, int N, int S,
+                                       int m, int32_t* samples, void* stream) {
     if (B < 0 || N < 0 || S < 0 || m < 1 || m > 8) return PH_ERR_INVALID_ARG;
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || S == 0) return PH_OK;
     if (!samples) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(sample_kernel, dim3(ph_ceil_div(S, 256), B), dim3(256), 0, (hipStream_t)stream, seed, n_valid, N, S,
-                       m, samples);
+    hipLaunchKernelGGL(sample_kernel, dim3(ph_ceil_div(S, 256), B), dim3(256), 0, (hipStream_t)stream, seed, item_key,
+                       n_valid, N, S, m, samples);
     return ph_launch_status();
+}
+
+extern "C" int ph_sample_minimal(uint32_t seed, const int32_t* n_valid, int B, int N, int S, int m, int32_t* samples,
+                                 void* stream) {
+    return ph_sample_minimal_keyed(seed, nullptr, n_valid, B, N, S, m, samples, stream);
 }
 
 extern "C" size_t ph_solve_essential_5pt_ws_bytes(int B, int S) {

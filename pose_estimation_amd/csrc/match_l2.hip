@@ -306,18 +306,19 @@ extern "C" int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float*
 }
 
 extern "C" size_t ph_match_l2_ws_bytes(int B, int nq, int nt, int dim, int precision) {
-    if (B <= 0 || nq <= 0 || nt <= 0) return 0;
+    if (B <= 0 || nq <= 0 || nt < 0) return 0;
+    if (nt == 0) nt = 1;              // an empty train view still runs the launch that writes the "no neighbour" outputs
     if (precision == PH_PRECISION_F16_RERANK && dim == 128) return plan_l2_filter(B, nq, nt).total;
     return plan_l2(B, nq, nt).total;
 }
 
-extern "C" int ph_match_l2_top2(const float* desc_q, const float* desc_t,
-                                const float* norm_q, const float* norm_t,
-                                const int32_t* view_q, const int32_t* view_t,
-                                const int32_t* n_q, const int32_t* n_t,
-                                int B, int nq, int nt, int dim, int precision,
-                                int32_t* idx, float* d1sq, float* d2sq,
-                                void* ws, size_t ws_bytes, void* stream) {
+extern "C" int ph_match_l2_top2_timed(const float* desc_q, const float* desc_t,
+                                      const float* norm_q, const float* norm_t,
+                                      const int32_t* view_q, const int32_t* view_t,
+                                      const int32_t* n_q, const int32_t* n_t,
+                                      int B, int nq, int nt, int dim, int precision,
+                                      int32_t* idx, float* d1sq, float* d2sq,
+                                      void* ws, size_t ws_bytes, void* stream, void* ev_begin, void* ev_end) {
     if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
     if (dim != 128 && dim != 64) return PH_ERR_UNSUPPORTED;
     if (precision != PH_PRECISION_F32 && precision != PH_PRECISION_F16_RERANK) return PH_ERR_UNSUPPORTED;
@@ -329,7 +330,7 @@ extern "C" int ph_match_l2_top2(const float* desc_q, const float* desc_t,
         const L2FilterPlan fp = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
         if (!ws || ws_bytes < fp.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
         return launch_l2_filter(desc_q, desc_t, norm_q, norm_t, view_q, view_t, n_q, n_t, B, nq, nt, idx, d1sq, d2sq, ws,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end);
     }
     const L2Plan p = plan_l2(B, nq, nt > 0 ? nt : 1);
     if (p.splits > 1 && (!ws || ws_bytes < p.total || !ph_aligned(ws, 16))) return PH_ERR_WORKSPACE;
@@ -337,18 +338,31 @@ extern "C" int ph_match_l2_top2(const float* desc_q, const float* desc_t,
     L2Partial* part = (L2Partial*)ws;
 
     const dim3 grid(ph_ceil_div(nq, 256), p.splits, B);
+    if (ev_begin && hipEventRecord((hipEvent_t)ev_begin, st) != hipSuccess) return PH_ERR_LAUNCH;
     if (dim == 128)
         hipLaunchKernelGGL(l2_top2_f32_kernel<128>, grid, dim3(256), 0, st, desc_q, desc_t, view_q, view_t, n_q, n_t,
                            nq, nt, p.splits, p.rows_per_split, norm_t, norm_q, idx, d1sq, d2sq, part);
     else
         hipLaunchKernelGGL(l2_top2_f32_kernel<64>, grid, dim3(256), 0, st, desc_q, desc_t, view_q, view_t, n_q, n_t,
                            nq, nt, p.splits, p.rows_per_split, norm_t, norm_q, idx, d1sq, d2sq, part);
+    if (ev_end && hipEventRecord((hipEvent_t)ev_end, st) != hipSuccess) return PH_ERR_LAUNCH;
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;
         hipLaunchKernelGGL(l2_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, norm_q, view_q, B,
                            nq, p.splits, idx, d1sq, d2sq);
     }
     return ph_launch_status();
+}
+
+extern "C" int ph_match_l2_top2(const float* desc_q, const float* desc_t,
+                                const float* norm_q, const float* norm_t,
+                                const int32_t* view_q, const int32_t* view_t,
+                                const int32_t* n_q, const int32_t* n_t,
+                                int B, int nq, int nt, int dim, int precision,
+                                int32_t* idx, float* d1sq, float* d2sq,
+                                void* ws, size_t ws_bytes, void* stream) {
+    return ph_match_l2_top2_timed(desc_q, desc_t, norm_q, norm_t, view_q, view_t, n_q, n_t, B, nq, nt, dim, precision, idx, d1sq,
+                                  d2sq, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
 extern "C" int ph_ratio_filter_l2(const int32_t* idx, const float* d1sq, const float* d2sq, int64_t n, float ratio,

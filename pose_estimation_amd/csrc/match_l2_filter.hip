@@ -662,7 +662,8 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
 
 int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm_q, const float* norm_t,
                      const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
-                     int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st) {
+                     int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st,
+                     hipEvent_t ev_begin, hipEvent_t ev_end) {
     const L2FilterPlan p = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
     float* tqmax = (float*)ws;                                   // Tmax[B] | Qmax[B]
     int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
@@ -675,8 +676,10 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
                            nt, p.tiles, B, tqmax, img);
         const int nqb = ph_ceil_div(nq, kWaves * 32 * kQT);
         const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
+        if (ev_begin && hipEventRecord(ev_begin, st) != hipSuccess) return PH_ERR_LAUNCH;
         hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, img, p.tiles, view_q, view_t, n_q, n_t,
                            nq, nt, p.rows_per_split, norm_q, tqmax, cnt, list, p.slots, nqb, B);
+        if (ev_end && hipEventRecord(ev_end, st) != hipSuccess) return PH_ERR_LAUNCH;
     }
     const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
     hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,

@@ -1,0 +1,273 @@
+// refine_e.hip — refinement of the winning relative pose of every pair (north_star: "the per-hypothesis refinement";
+// VERDICT r1 item 6).  No reference code: the reference refines only inside cv2.solvePnP (main.py:101-104), one
+// view against a known board; this is the two-view analogue, batched.  (Its CPU restatement for the tests is named in DESIGN.md §5.)
+//
+//   minimise  sum_i min(r_i^2, c^2),  r_i = (x2' E x1) / sqrt((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2),
+//   E = [t]x R, |t| = 1: 5 degrees of freedom, R <- exp([dw]x) R, t <- normalise(t + d3 b1 + d4 b2).
+//
+// One 256-thread block per pair, float64.  A pass over the pair's correspondences (coalesced SoA loads, points on
+// lanes) produces the normal equations of the correspondences inside the truncation (15 + 5 sums), their sum of
+// squares, their number and the number of valid correspondences; the sums are reduced by wave shuffles and a 4-row
+// LDS table; thread 0 solves the damped 5x5 system (Cholesky, Marquardt scaling) and proposes the next pose, whose
+// pass is both its cost and — when it is accepted — the next normal equations: ONE pass per iteration.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kNT = 256;
+constexpr int kNW = kNT / 64;
+constexpr int kSums = 23;          // 15 (J'J upper) + 5 (J'r) + ssq + n_inside + n_valid
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ void skew_mul(const double* v, const double (&M)[9], double (&out)[9]) {   // [v]x M
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        out[c] = -v[2] * M[3 + c] + v[1] * M[6 + c];
+        out[3 + c] = v[2] * M[c] - v[0] * M[6 + c];
+        out[6 + c] = -v[1] * M[c] + v[0] * M[3 + c];
+    }
+}
+
+// b1 = normalise(t x e_a), a = axis of the smallest |t_a| (lowest index on ties); b2 = t x b1
+__device__ __forceinline__ void tangent_basis(const double* t, double* b1, double* b2) {
+    const double a0 = fabs(t[0]), a1 = fabs(t[1]), a2 = fabs(t[2]);
+    const int a = (a0 <= a1 && a0 <= a2) ? 0 : (a1 <= a2 ? 1 : 2);
+    if (a == 0) { b1[0] = 0.0; b1[1] = t[2]; b1[2] = -t[1]; }
+    else if (a == 1) { b1[0] = -t[2]; b1[1] = 0.0; b1[2] = t[0]; }
+    else { b1[0] = t[1]; b1[1] = -t[0]; b1[2] = 0.0; }
+    const double n = 1.0 / sqrt(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
+    b1[0] *= n; b1[1] *= n; b1[2] *= n;
+    b2[0] = t[1] * b1[2] - t[2] * b1[1];
+    b2[1] = t[2] * b1[0] - t[0] * b1[2];
+    b2[2] = t[0] * b1[1] - t[1] * b1[0];
+}
+
+__device__ __forceinline__ void exp_so3(const double* w, double (&R)[9]) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th = sqrt(th2);
+    double a, b;                                   // R = I + a [w]x + b [w]x^2
+    if (th < 1e-12) { a = 1.0; b = 0.0; }
+    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+    const double x = w[0], y = w[1], z = w[2];
+    R[0] = 1.0 - b * (y * y + z * z); R[1] = -a * z + b * x * y;        R[2] = a * y + b * x * z;
+    R[3] = a * z + b * x * y;         R[4] = 1.0 - b * (x * x + z * z); R[5] = -a * x + b * y * z;
+    R[6] = -a * y + b * x * z;        R[7] = a * x + b * y * z;         R[8] = 1.0 - b * (x * x + y * y);
+}
+
+struct PassOut { double s[kSums]; };
+
+// One pass: every thread accumulates its correspondences; returns the block-wide sums in thread 0's copy (all
+// threads get them through `red`, which the caller may read after the trailing barrier).
+__device__ __forceinline__ void pass(const double* Rsh, const double* tsh, const float* __restrict__ x1, const float* __restrict__ y1,
+                                     const float* __restrict__ x2, const float* __restrict__ y2,
+                                     const uint64_t* __restrict__ mask, int nv, double c_sq, double (*red)[kSums]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double R[9], t[3], E[9], G[5][9], b1[3], b2[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rsh[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = tsh[k];
+    skew_mul(t, R, E);
+    tangent_basis(t, b1, b2);
+    {
+        // G_k = [t]x [e_k]x R (k = 0..2), [b1]x R, [b2]x R
+        double M[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double e[3] = {0.0, 0.0, 0.0};
+            e[k] = 1.0;
+            skew_mul(e, R, M);
+            skew_mul(t, M, G[k]);
+        }
+        skew_mul(b1, R, G[3]);
+        skew_mul(b2, R, G[4]);
+    }
+    double acc[kSums];
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
+    for (int i0 = 0; i0 < nv; i0 += kNT) {
+        const int i = i0 + tid;
+        bool on = i < nv;
+        if (on && mask) on = (mask[i >> 6] >> (i & 63)) & 1ull;
+        if (!on) continue;
+        const double a1 = x1[i], c1 = y1[i], a2 = x2[i], c2 = y2[i];
+        const double e0 = E[0] * a1 + E[1] * c1 + E[2], e1 = E[3] * a1 + E[4] * c1 + E[5], e2 = E[6] * a1 + E[7] * c1 + E[8];
+        const double f0 = E[0] * a2 + E[3] * c2 + E[6], f1 = E[1] * a2 + E[4] * c2 + E[7];
+        const double num = a2 * e0 + c2 * e1 + e2;
+        const double den = fmax(e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1, 1e-300);
+        const double isq = 1.0 / sqrt(den);
+        const double r = num * isq;
+        acc[22] += 1.0;
+        if (!(r * r < c_sq)) continue;
+        double J[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const double* g = G[k];
+            const double g0 = g[0] * a1 + g[1] * c1 + g[2], g1 = g[3] * a1 + g[4] * c1 + g[5], g2 = g[6] * a1 + g[7] * c1 + g[8];
+            const double h0 = g[0] * a2 + g[3] * c2 + g[6], h1 = g[1] * a2 + g[4] * c2 + g[7];
+            const double dnum = a2 * g0 + c2 * g1 + g2;
+            const double dden = 2.0 * (e0 * g0 + e1 * g1 + f0 * h0 + f1 * h1);
+            J[k] = dnum * isq - 0.5 * num * dden * isq / den;
+        }
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int c = a; c < 5; ++c) acc[q++] += J[a] * J[c];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) acc[15 + a] += J[a] * r;
+        acc[20] += r * r;
+        acc[21] += 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kSums; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < kSums; ++k) red[wave][k] = acc[k];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
+                                                                   const float* __restrict__ x2, const float* __restrict__ y2,
+                                                                   const uint64_t* __restrict__ mask, const int32_t* __restrict__ n_valid,
+                                                                   int N, double c_sq, int max_iters, float* __restrict__ pose_rt,
+                                                                   int stride, double* __restrict__ rms, int32_t* __restrict__ n_inl,
+                                                                   int32_t* __restrict__ iters_out) {
+    __shared__ double red[kNW][kSums];
+    __shared__ double sh_R[9], sh_t[3], sh_Rc[9], sh_tc[3];
+    __shared__ int sh_flag;                 // 0: trial pose ready, 1: stop, 2: no trial this iteration (system not p.d.)
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    const size_t o = (size_t)b * N;
+    x1 += o; y1 += o; x2 += o; y2 += o;
+    if (mask) mask += (size_t)b * ((N + 63) / 64);
+    float* P = pose_rt + (size_t)b * stride;
+
+    if (tid == 0) {
+        double t[3] = {(double)P[9], (double)P[10], (double)P[11]};
+        const double nt = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        bool ok = nt > 0.0 && nt < 1e300;                         // NaN fails both
+        for (int k = 0; k < 9; ++k) { sh_R[k] = (double)P[k]; ok = ok && fabs(sh_R[k]) <= 2.0; }
+        for (int k = 0; k < 3; ++k) sh_t[k] = ok ? t[k] / nt : 0.0;
+        sh_flag = ok ? 0 : 1;
+    }
+    __syncthreads();
+    const bool usable = sh_flag == 0;
+    __syncthreads();
+
+    // thread 0's accepted state
+    double A[15], g[5], cost = 0.0, ssq = 0.0, nin = 0.0, lambda = 1e-3;
+    int it = 0;
+    if (usable) {
+        pass(sh_R, sh_t, x1, y1, x2, y2, mask, nv, c_sq, red);
+        if (tid == 0) {
+            double s[kSums];
+            for (int k = 0; k < kSums; ++k) { s[k] = 0.0; for (int w = 0; w < kNW; ++w) s[k] += red[w][k]; }
+            for (int k = 0; k < 15; ++k) A[k] = s[k];
+            for (int k = 0; k < 5; ++k) g[k] = s[15 + k];
+            ssq = s[20]; nin = s[21];
+            cost = ssq + (s[22] - nin) * c_sq;
+            sh_flag = (s[22] < 6.0) ? 1 : 0;
+        }
+        __syncthreads();
+        for (; it < max_iters;) {
+            if (sh_flag == 1) break;                               // uniform: read after a barrier
+            ++it;
+            __syncthreads();                                       // everybody has read sh_flag before thread 0 rewrites it
+            if (tid == 0) {
+                double M[5][5], L[5][5], d[5];
+                int q = 0;
+                for (int a = 0; a < 5; ++a)
+                    for (int c = a; c < 5; ++c) { M[a][c] = A[q]; M[c][a] = A[q]; ++q; }
+                for (int a = 0; a < 5; ++a) M[a][a] += lambda * M[a][a] + 1e-300;
+                bool ok = true;
+                for (int a = 0; a < 5 && ok; ++a)
+                    for (int c = 0; c <= a; ++c) {
+                        double v = M[a][c];
+                        for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
+                        if (a == c) { if (!(v > 0.0)) { ok = false; break; } L[a][a] = sqrt(v); }
+                        else L[a][c] = v / L[c][c];
+                    }
+                if (!ok) {
+                    lambda *= 10.0;
+                    sh_flag = lambda > 1e12 ? 1 : 2;
+                } else {
+                    for (int a = 0; a < 5; ++a) { double v = -g[a]; for (int k = 0; k < a; ++k) v -= L[a][k] * d[k]; d[a] = v / L[a][a]; }
+                    for (int a = 4; a >= 0; --a) { double v = d[a]; for (int k = a + 1; k < 5; ++k) v -= L[k][a] * d[k]; d[a] = v / L[a][a]; }
+                    double dR[9], Rcur[9], b1[3], b2[3], tcur[3];
+                    exp_so3(d, dR);
+                    for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
+                    for (int k = 0; k < 3; ++k) tcur[k] = sh_t[k];
+                    for (int r = 0; r < 3; ++r)
+                        for (int c = 0; c < 3; ++c)
+                            sh_Rc[3 * r + c] = dR[3 * r] * Rcur[c] + dR[3 * r + 1] * Rcur[3 + c] + dR[3 * r + 2] * Rcur[6 + c];
+                    tangent_basis(tcur, b1, b2);
+                    double tn[3], n2 = 0.0;
+                    for (int k = 0; k < 3; ++k) { tn[k] = tcur[k] + d[3] * b1[k] + d[4] * b2[k]; n2 += tn[k] * tn[k]; }
+                    const double inv = 1.0 / sqrt(n2);
+                    for (int k = 0; k < 3; ++k) sh_tc[k] = tn[k] * inv;
+                    double dd = 0.0;
+                    for (int a = 0; a < 5; ++a) dd += d[a] * d[a];
+                    red[0][0] = dd;                                // handed to the accept step below (thread 0 only)
+                    sh_flag = 0;
+                }
+            }
+            __syncthreads();
+            const int flag = sh_flag;
+            if (flag != 0) continue;                               // 1: the loop head stops; 2: next iteration re-solves
+            double dd = 0.0;
+            if (tid == 0) dd = red[0][0];
+            __syncthreads();
+            pass(sh_Rc, sh_tc, x1, y1, x2, y2, mask, nv, c_sq, red);
+            if (tid == 0) {
+                double s[kSums];
+                for (int k = 0; k < kSums; ++k) { s[k] = 0.0; for (int w = 0; w < kNW; ++w) s[k] += red[w][k]; }
+                const double cn = s[20] + (s[22] - s[21]) * c_sq;
+                if (cn < cost) {
+                    const bool done = (cost - cn) <= 1e-12 * fmax(cost, 1e-300) || dd < 1e-26;
+                    for (int k = 0; k < 15; ++k) A[k] = s[k];
+                    for (int k = 0; k < 5; ++k) g[k] = s[15 + k];
+                    ssq = s[20]; nin = s[21]; cost = cn;
+                    for (int k = 0; k < 9; ++k) sh_R[k] = sh_Rc[k];
+                    for (int k = 0; k < 3; ++k) sh_t[k] = sh_tc[k];
+                    lambda = fmax(lambda * 0.1, 1e-12);
+                    sh_flag = done ? 1 : 0;
+                } else {
+                    lambda *= 10.0;
+                    sh_flag = lambda > 1e12 ? 1 : 0;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        if (it > 0)                                                // no iteration ran: the caller's row stays bit for bit
+            for (int k = 0; k < 9; ++k) P[k] = (float)sh_R[k];
+        if (it > 0)
+            for (int k = 0; k < 3; ++k) P[9 + k] = (float)sh_t[k];
+        if (rms) rms[b] = nin > 0.0 ? sqrt(ssq / nin) : 0.0;
+        if (n_inl) n_inl[b] = (int32_t)nin;
+        if (iters_out) iters_out[b] = it;
+    }
+}
+
+}  // namespace
+
+extern "C" int ph_refine_relative_pose(const float* x1, const float* y1, const float* x2, const float* y2,
+                                       const uint64_t* mask, const int32_t* n_valid, int B, int N, float trunc_sq,
+                                       int max_iters, float* pose_rt, int stride, double* rms, int32_t* n_inliers,
+                                       int32_t* iters, void* stream) {
+    if (B < 0 || N < 0 || max_iters < 0 || stride < 12 || !(trunc_sq > 0.0f)) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!x1 || !y1 || !x2 || !y2 || !pose_rt) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(refine_relative_pose_kernel, dim3(B), dim3(kNT), 0, (hipStream_t)stream, x1, y1, x2, y2, mask, n_valid,
+                       N, (double)trunc_sq, max_iters, pose_rt, stride, rms, n_inliers, iters);
+    return ph_launch_status();
+}

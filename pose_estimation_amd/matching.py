@@ -74,7 +74,7 @@ def row_sqnorm(table):
 
 
 def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, precision=L.PRECISION_F16_RERANK,
-             norm_q=None, norm_t=None):
+             norm_q=None, norm_t=None, kernel_events=None):
     """Squared-L2 top-2.  Returns (idx int32, d1sq f32, d2sq f32), each ``[B, nq]``.
 
     precision picks the algorithm, not the result (both follow the f32 fma-chain contract bit for bit):
@@ -82,6 +82,8 @@ def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, preci
     candidates with one fp16 MFMA product per score (inside a proven error band) and re-ranks them with the exact chain.
 
     norm_q / norm_t: cached ``row_sqnorm`` of the tables (computed here when not given).
+    kernel_events: optional pair of raw hipEvent_t handles (ints) recorded around the call's dominant kernel alone
+    (``ph_match_l2_top2_timed``; measurement only, at most one launch chunk).
     """
     lib = L.load()
     desc_q = L.dev(desc_q, torch.float32, "desc_q")
@@ -111,10 +113,13 @@ def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, preci
         t = desc_t if view_t is not None else desc_t[s:e]
         qn = norm_q if view_q is not None else norm_q[s:e]
         tn = norm_t if view_t is not None else norm_t[s:e]
-        L.check(lib.ph_match_l2_top2(L.ptr(q), L.ptr(t), L.ptr(qn), L.ptr(tn), L.ptr(sl(view_q)), L.ptr(sl(view_t)),
-                                     L.ptr(sl(n_q)), L.ptr(sl(n_t)), nb, nq, nt, dim, precision,
-                                     L.ptr(idx[s:e]), L.ptr(d1[s:e]), L.ptr(d2[s:e]),
-                                     L.ptr(ws), wsb, L.stream_ptr()), "ph_match_l2_top2")
+        args = (L.ptr(q), L.ptr(t), L.ptr(qn), L.ptr(tn), L.ptr(sl(view_q)), L.ptr(sl(view_t)),
+                L.ptr(sl(n_q)), L.ptr(sl(n_t)), nb, nq, nt, dim, precision,
+                L.ptr(idx[s:e]), L.ptr(d1[s:e]), L.ptr(d2[s:e]), L.ptr(ws), wsb, L.stream_ptr())
+        if kernel_events is not None:
+            L.check(lib.ph_match_l2_top2_timed(*args, kernel_events[0], kernel_events[1]), "ph_match_l2_top2_timed")
+        else:
+            L.check(lib.ph_match_l2_top2(*args), "ph_match_l2_top2")
     return idx, d1, d2
 
 

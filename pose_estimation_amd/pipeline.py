@@ -24,6 +24,8 @@ import torch
 
 from . import geometry, matching, ransac, triangulation
 
+REFINE_TRUNC = 3.0          # truncation of the refinement's loss, in RANSAC thresholds
+REFINE_ITERS = 4            # LM iterations (one pass over the correspondences each): converged to < 0.001 deg by then
 STATUS_OK = 1.0
 STATUS_DEGENERATE = 0.0
 
@@ -42,10 +44,12 @@ class Front:
     copied: torch.cuda.Event             # None with decompose="device"
     want_points: bool = False
     extra: dict = field(default_factory=dict)
+    opts: dict = field(default_factory=dict)
 
 
 def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
-                        n_samples=410, seed=0, decompose="device") -> Front:
+                        n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False,
+                        refine=True) -> Front:
     """Everything up to the inlier mask, plus (decompose="host") an asynchronous copy of the winning E of every pair.
 
     match: callable returning (idx, d1, d2, kind) with kind "l2" or "hamming",
@@ -53,20 +57,29 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     kp_q/kp_t: [V, n, 2] normalised keypoints; view_q/view_t: int32 [B] (device) or None.
     E_hyp: [B, H, 9] float32 device tensor of essential-matrix hypotheses, or None: then they are
            generated on the device from `n_samples` Philox-drawn minimal samples of the pair's own
-           matches by the 5-point solver (10 hypothesis slots per sample, H = 10*n_samples).
+           matches by the 5-point solver (10 hypothesis slots per sample, H = 10*n_samples; a slot holds a model
+           only for a real root — ``want_counts`` puts the per-sample numbers of real models, int32 [B, n_samples],
+           into ``Front.extra["n_solutions"]``).
+    item_key: per-pair Philox keys (int tensor [B], e.g. global pair ids) so that a pair draws the same minimal
+           samples in whatever batch slot, chunk or rank it is processed; None = position in the batch.
     """
     idx, d1, d2, kind = match()
     keep = (matching.ratio_filter_l2 if kind == "l2" else matching.ratio_filter_hamming)(idx, d1, d2, ratio)
     m = matching.compact_matches(idx, keep, kp_q, kp_t, view_q, view_t, want_indices=False)
     pts = (m["x1"], m["y1"], m["x2"], m["y2"])
+    extra = {}
+    front_opts = dict(thr_sq=float(thr_sq), refine=bool(refine))
     if E_hyp is None:
-        samples = ransac.sample_minimal(seed, m["n_match"], pts[0].shape[1], n_samples)
-        E_hyp = ransac.solve_essential_5pt(*pts, samples)
+        samples = ransac.sample_minimal(seed, m["n_match"], pts[0].shape[1], n_samples, item_key=item_key)
+        if want_counts:
+            E_hyp, extra["n_solutions"] = ransac.solve_essential_5pt(*pts, samples, want_counts=True)
+        else:
+            E_hyp = ransac.solve_essential_5pt(*pts, samples)
     cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"], bailout=True)    # only the winner is read
     bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_essential(E_hyp, bi, *pts, thr_sq, m["n_match"])
     if decompose == "device":
-        return Front(pts, m["n_match"], E_hyp, bi, bc, mask, None, None, want_points)
+        return Front(pts, m["n_match"], E_hyp, bi, bc, mask, None, None, want_points, extra, front_opts)
     if decompose != "host":
         raise ValueError("decompose must be 'device' or 'host'")
     B = E_hyp.shape[0]
@@ -75,7 +88,7 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     host.copy_(E_best, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    return Front(pts, m["n_match"], E_hyp, bi, bc, mask, host, ev, want_points)
+    return Front(pts, m["n_match"], E_hyp, bi, bc, mask, host, ev, want_points, extra, front_opts)
 
 
 def relative_pose_back(f: Front):
@@ -93,8 +106,13 @@ def relative_pose_back(f: Front):
     xyz, front = triangulation.triangulate(P1d, P2d, *f.pts, n_valid=f.n_match, mask=f.mask,
                                            want_points=f.want_points, want_front=True)
     table, win = triangulation.pose_table(P2d, front, f.best_count, f.n_match, f.best_idx, min_inliers=5)
+    if f.opts.get("refine", False):
+        # the cheirality winner, refined on all the pair's correspondences under a loss truncated at 3 x the RANSAC
+        # threshold (north_star's "per-hypothesis refinement", here on the device: no host round trip)
+        ransac.refine_relative_pose(*f.pts, table, REFINE_TRUNC * REFINE_TRUNC * f.opts["thr_sq"], n_valid=f.n_match,
+                                    max_iters=REFINE_ITERS)
     out = dict(table=table, E_hyp=f.E_hyp, n_match=f.n_match, best_idx=f.best_idx, best_count=f.best_count,
-               mask=f.mask, front=front, win=win)
+               mask=f.mask, front=front, win=win, **f.extra)
     if f.want_points:
         out["xyz"] = xyz[torch.arange(B, device=dev), win.long()]
         out["pts"] = f.pts
@@ -102,11 +120,12 @@ def relative_pose_back(f: Front):
 
 
 def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
-                        n_samples=410, seed=0, decompose="device"):
+                        n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False, refine=True):
     """front + back for one batch of B pairs.  Returns dict(table [B,16] device f32, n_match, best_idx,
     best_count, mask, E_hyp, front, win and, with want_points, xyz / pts)."""
     return relative_pose_back(relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio,
-                                                  want_points, n_samples, seed, decompose))
+                                                  want_points, n_samples, seed, decompose, item_key, want_counts,
+                                                  refine))
 
 
 def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096, seed=0, refine=True, max_iters=20):

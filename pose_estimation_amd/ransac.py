@@ -26,14 +26,22 @@ def _models(m, B, width, name):
     return m
 
 
-def sample_minimal(seed, n_valid, N, n_samples, m=5):
-    """Counter-based (Philox4x32-10) minimal samples: int32 ``[B, n_samples, m]`` distinct indices per row."""
+def sample_minimal(seed, n_valid, N, n_samples, m=5, item_key=None):
+    """Counter-based (Philox4x32-10) minimal samples: int32 ``[B, n_samples, m]`` distinct indices per row.
+
+    item_key: int32/int64 ``[B]`` device tensor of per-item Philox keys (e.g. global pair ids, taken mod 2^32) or None
+    (= the item's position in the batch): with keys, an item draws the same samples wherever it sits in a batch."""
     lib = L.load()
     n_valid = L.dev(n_valid, torch.int32, "n_valid")
     B = n_valid.numel()
     out = torch.empty((B, n_samples, m), dtype=torch.int32, device=n_valid.device)
-    L.check(lib.ph_sample_minimal(int(seed) & 0xFFFFFFFF, L.ptr(n_valid), B, int(N), int(n_samples), int(m), L.ptr(out),
-                                  L.stream_ptr()), "ph_sample_minimal")
+    if item_key is not None:
+        if not isinstance(item_key, torch.Tensor) or not item_key.is_cuda or item_key.numel() != B:
+            raise ValueError("item_key must be a device tensor with one key per item")
+        item_key = (item_key.to(torch.int64) & 0xFFFFFFFF).to(torch.int32) if item_key.dtype != torch.int32 else item_key
+        item_key = item_key.contiguous()
+    L.check(lib.ph_sample_minimal_keyed(int(seed) & 0xFFFFFFFF, L.ptr(item_key), L.ptr(n_valid), B, int(N), int(n_samples),
+                                        int(m), L.ptr(out), L.stream_ptr()), "ph_sample_minimal_keyed")
     return out
 
 
@@ -103,6 +111,36 @@ def decompose_essential(E, sel=None):
     L.check(lib.ph_decompose_essential(L.ptr(E), L.ptr(sel), B, H, L.ptr(P1), L.ptr(P2), L.stream_ptr()),
             "ph_decompose_essential")
     return P1, P2
+
+
+def refine_relative_pose(x1, y1, x2, y2, pose_rt, trunc_sq, n_valid=None, mask=None, max_iters=4, want_stats=False):
+    """LM refinement of B relative poses IN PLACE on the truncated Sampson cost (``ph_refine_relative_pose``).
+
+    pose_rt: float32 ``[B, stride >= 12]`` rows of R (9, row-major) | t (3) — e.g. the ``[B, 16]`` pose table.
+    trunc_sq: squared truncation distance in the points' units (the pipeline uses 9 x the RANSAC thr_sq).
+    Returns pose_rt, or (pose_rt, rms f64 [B], n_inliers i32 [B], iters i32 [B]) with want_stats."""
+    lib = L.load()
+    x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
+    B, N = x1.shape
+    pose_rt = L.dev(pose_rt, torch.float32, "pose_rt")
+    if pose_rt.dim() != 2 or pose_rt.shape[0] != B or pose_rt.shape[1] < 12:
+        raise ValueError("pose_rt must be [B, >= 12] float32")
+    if not pose_rt.is_contiguous():
+        raise ValueError("pose_rt is refined in place and must be contiguous")
+    if mask is not None:
+        mask = L.dev(mask, torch.int64, "mask")
+        if mask.shape != (B, (N + 63) // 64):
+            raise ValueError("mask must be [B, ceil(N/64)] 64-bit words")
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    rms = nin = iters = None
+    if want_stats:
+        rms = torch.empty((B,), dtype=torch.float64, device=x1.device)
+        nin = torch.empty((B,), dtype=torch.int32, device=x1.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=x1.device)
+    L.check(lib.ph_refine_relative_pose(L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(mask), L.ptr(n_valid), B, N,
+                                        float(trunc_sq), int(max_iters), L.ptr(pose_rt), pose_rt.shape[1], L.ptr(rms),
+                                        L.ptr(nin), L.ptr(iters), L.stream_ptr()), "ph_refine_relative_pose")
+    return (pose_rt, rms, nin, iters) if want_stats else pose_rt
 
 
 def pose_from_projection(P, sel=None, K4=None):

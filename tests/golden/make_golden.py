@@ -33,6 +33,31 @@ def quaternions():
               open(os.path.join(HERE, "quaternions.json"), "w"), indent=0)
 
 
+def rodrigues():
+    """cv2.Rodrigues (main.py:122) == scipy Rotation.from_rotvec(r).as_matrix(): the one piece of the OpenCV side
+    that the reference's own dependency set can pin.  Stored per case: the rotation vector, SciPy's matrix, SciPy's
+    rotation vector back from that matrix (the inverse direction) and main.py:138-141's quaternion of the TRANSPOSE
+    (the camera-to-world rotation the reference converts), in SciPy's own sign."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(2024)
+    vecs = [rng.normal(0, 1.2, 3) for _ in range(40)]
+    vecs += [np.zeros(3), np.array([1e-13, -2e-13, 3e-14]), np.array([1e-9, 0, 0]), np.array([0, -3e-7, 1e-7]),
+             np.array([1e-4, 2e-4, -1e-4])]                                                  # theta -> 0
+    for th in (np.pi - 1e-3, np.pi - 1e-5, np.pi - 1e-7, np.pi - 1e-9):                      # theta -> pi
+        for ax in (np.array([1.0, 0, 0]), np.array([0.6, -0.48, 0.64]), np.array([0.0, 0.6, 0.8]), np.array([-0.36, 0.48, -0.8])):
+            vecs.append(th * ax / np.linalg.norm(ax))
+    vecs += [np.array([0.0, 0.0, 3.0]), np.array([2.0, -2.0, 0.5]), np.array([0.0, np.pi / 2, 0.0])]
+    cases = []
+    for r in vecs:
+        rot = Rotation.from_rotvec(r)
+        M = rot.as_matrix()
+        cases.append({"rvec": [float(x) for x in r], "R": M.tolist(), "rvec_back": Rotation.from_matrix(M).as_rotvec().tolist(),
+                      "quat_xyzw_of_Rt": Rotation.from_matrix(M.T).as_quat().tolist()})
+    json.dump({"source": "scipy " + __import__("scipy").__version__ + " Rotation.from_rotvec(r).as_matrix() / from_matrix(R).as_rotvec() / "
+                         "from_matrix(R.T).as_quat()", "cases": cases},
+              open(os.path.join(HERE, "rodrigues.json"), "w"), indent=0)
+
+
 def matching():
     rng = np.random.default_rng(7)
     q = rng.integers(0, 256, (96, 32), dtype=np.uint8)
@@ -91,5 +116,9 @@ def board():
 
 
 if __name__ == "__main__":
-    quaternions(); matching(); scoring(); board()
+    if len(sys.argv) > 1:                      # regenerate only the named fixtures, e.g. `make_golden.py rodrigues`
+        for name in sys.argv[1:]:
+            globals()[name]()
+    else:
+        quaternions(); rodrigues(); matching(); scoring(); board()
     print("golden fixtures written to", HERE)

@@ -1,0 +1,90 @@
+"""configs[3] (SURVEY.md §8d cfg 4) end to end on one GPU: a 40-view slice of the 1,000-view scene at 8,192
+features, all 780 pairs through the runner that `benchmarks/configs.py --cfg 4` uses (`sharding.run_pair_list` +
+`allpairs.AllPairs`), once unsharded and once as two interleaved `pair_id % 2` shards merged by the same index
+arithmetic as the final gather.  Workload anchor: the reference's all-pairs loop, /root/reference/main.py:458-463.
+
+Bars: sharded == unsharded row for row (bit-exact: RANSAC samples are keyed by the global pair id); a sampled set
+of pairs' matches / inlier counts / masks bit-exact against the CPU oracle; poses near the ground truth.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from pose_estimation_amd import geometry, matching, pipeline, sharding, synthetic
+from pose_estimation_amd.allpairs import AllPairs
+
+pytestmark = pytest.mark.gpu
+
+V, N_FEAT, SAMPLES, CHUNK = 40, 8192, 96, 64
+THR_SQ = float(np.float32((1.5 / synthetic.FX) ** 2))
+
+
+def _run(run, vi, vj, rank, world, dev):
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    return sharding.run_pair_list(vi, vj, run.chunk, rank, world, chunk=CHUNK,
+                                  stream_ctx=lambda k: torch.cuda.stream(streams[k % 2]),
+                                  sync=torch.cuda.synchronize, device=dev)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_cfg4_slice_sharded_equals_unsharded_and_oracle(device, f32):
+    gen = synthetic.float_views if f32 else synthetic.binary_views
+    sc = gen(V, N_FEAT, seed=1004, config=4)
+    desc = torch.from_numpy(sc["desc"]).to(device)
+    kp = torch.from_numpy(sc["kp"]).to(device)
+    norms = matching.row_sqnorm(desc) if f32 else None
+    vi, vj = synthetic.all_pairs(V)
+    n = len(vi)
+    assert n == 780
+    run = AllPairs(desc, kp, norms, THR_SQ, SAMPLES, f32)
+
+    full, local, mine = _run(run, vi, vj, 0, 1, device)                # world 1: the gather is the identity
+    assert full.shape == (n, 16) and torch.equal(mine, torch.arange(n))
+    # two shards, processed one after the other on the one GPU, merged like all_gather_into_tensor + interleave
+    per = (n + 1) // 2
+    stacked = torch.zeros((2 * per, 16), dtype=torch.float32, device=device)
+    for r in range(2):
+        _, loc, ids = _run(run, vi, vj, r, 2, device)
+        assert torch.equal(ids, sharding.shard_indices(n, r, 2)) and loc.shape[0] == sharding.shard_size(n, r, 2)
+        stacked[r * per: r * per + loc.shape[0]] = loc
+    merged = sharding.interleave_shards(stacked, n, 2)
+    assert torch.equal(merged, full), "sharded run differs from the unsharded run"
+
+    tab = full.cpu().numpy()
+    assert (tab[:, 15] == pipeline.STATUS_OK).all()
+    rerr = np.array([geometry.rotation_angle_deg(tab[p, :9].reshape(3, 3),
+                                                 synthetic.relative_pose(sc["R"][vi[p]], sc["t"][vi[p]], sc["R"][vj[p]], sc["t"][vj[p]])[0])
+                     for p in range(n)])
+    terr = np.array([geometry.direction_angle_deg(tab[p, 9:12],
+                                                  synthetic.relative_pose(sc["R"][vi[p]], sc["t"][vi[p]], sc["R"][vj[p]], sc["t"][vj[p]])[1])
+                     for p in range(n)])
+    assert np.mean((rerr < 1.0) & (terr < 1.0)) == 1.0 and np.median(rerr) < 0.05
+
+    # ---- sampled pairs against the CPU oracle: matches, the winner's count, its mask — bit-exact
+    for p in (0, 391, 779):
+        q = torch.tensor([vi[p]], dtype=torch.int32, device=device)
+        t = torch.tensor([vj[p]], dtype=torch.int32, device=device)
+        key = torch.tensor([p], dtype=torch.int32, device=device)
+        if f32:
+            match = lambda: (*matching.match_l2(desc, desc, q, t, norm_q=norms, norm_t=norms), "l2")
+            idx, d1, d2 = orc.match_l2_top2(sc["desc"][vi[p]], sc["desc"][vj[p]])
+            keep = orc.ratio_filter_l2(idx, d1, d2, run.ratio)
+        else:
+            match = lambda: (*matching.match_hamming(desc, desc, q, t), "hamming")
+            idx, d1, d2 = orc.match_hamming_top2(sc["desc"][vi[p]], sc["desc"][vj[p]])
+            keep = orc.ratio_filter_hamming(idx, d1, d2, run.ratio)
+        out = pipeline.relative_pose_batch(match, kp, kp, q, t, None, THR_SQ, ratio=run.ratio, n_samples=SAMPLES,
+                                           seed=AllPairs.SEED, item_key=key, want_counts=True)
+        assert torch.equal(out["table"][0], full[p]), "a pair alone differs from the same pair inside a chunk"
+        m = orc.compact_matches(idx, keep, sc["kp"][vi[p]], sc["kp"][vj[p]])
+        nm = m["n_match"]
+        assert nm == int(tab[p, 13]) and nm > 1000
+        pts = [m[k][:nm] for k in ("x1", "y1", "x2", "y2")]
+        E = out["E_hyp"].cpu().numpy()[0]
+        cnt = orc.score_essential(E, *pts, np.float32(THR_SQ))
+        bi, bc = orc.select_best(cnt)
+        assert (bi, bc) == (int(tab[p, 14]), int(tab[p, 12]))
+        assert np.array_equal(orc.inlier_mask_essential(E[bi], *pts, np.float32(THR_SQ), N_FEAT),
+                              out["mask"].cpu().numpy().view(np.uint64)[0])
+        assert int(out["n_solutions"].sum()) == int((np.abs(E).sum(axis=1) > 0).sum())

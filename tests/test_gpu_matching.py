@@ -264,3 +264,17 @@ def test_row_sqnorm_bit_exact(device, rows, dim):
     a = rng.standard_normal((rows, dim)).astype(np.float32)
     got = matching.row_sqnorm(_t(a[None], device)).cpu().numpy()[0]
     assert np.array_equal(got.view(np.uint32), orc.row_sqnorm(a).view(np.uint32))
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_l2_empty_train(device, precision):
+    """A [V, 0, 128] train table: every query gets PH_NO_INDEX / +inf, for both algorithms (the Hamming twin of this
+    case is test_hamming_empty_train)."""
+    from pose_estimation_amd import _lib as L
+    rng = np.random.default_rng(0)
+    q = torch.from_numpy(synthetic.sift_like(rng, 70, 128)[None]).to(device)
+    t = torch.empty((1, 0, 128), dtype=torch.float32, device=device)
+    idx, d1, d2 = matching.match_l2(q, t, precision=precision)
+    assert (idx == L.PH_NO_INDEX).all() and torch.isinf(d1).all() and torch.isinf(d2).all()
+    keep = matching.ratio_filter_l2(idx, d1, d2, 0.75)
+    assert int(keep.sum()) == 0

@@ -1,0 +1,115 @@
+"""ph_refine_relative_pose on the GPU against its NumPy restatement (oracle/refine_e.py), and — for the SciPy pins —
+the device Rodrigues / quaternion against tests/golden/rodrigues.json.
+
+Bars (north_star): CPU path vs GPU path rotation / translation angular difference < 0.1 degrees — here the two LM
+implementations agree to 1e-4 degrees; the refined pose recovers the ground truth to a few hundredths of a degree.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from oracle import refine_e
+from pose_estimation_amd import board, geometry, ransac, synthetic
+from tests.test_scipy_pins import branch_tie
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def test_refine_relative_pose_matches_numpy_twin(device):
+    from tests.test_refine_e import _scene, ransac_start
+    B, N = 6, 2048
+    thr_sq = np.float32((1.0 / synthetic.FX) ** 2)
+    c_sq = float(np.float32(9.0) * thr_sq)
+    n_valid = np.array([N, 1500, 700, 64, 5, N], np.int32)
+    pts = np.zeros((4, B, N), np.float32)
+    table = np.zeros((B, 16), np.float32)
+    truth = []
+    rng = np.random.default_rng(3)
+    for b in range(B):
+        R, t, x1, x2, _ = _scene(40 + b, n=N)
+        pts[0, b], pts[1, b], pts[2, b], pts[3, b] = x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1]
+        R0, t0 = ransac_start(R, t, x1, x2, thr_sq, b)
+        table[b, :9] = R0.reshape(9); table[b, 9:12] = t0 / np.linalg.norm(t0); table[b, 12:] = [7, 8, 9, 1]
+        truth.append((R, t))
+    table[5, 9:12] = 0.0                                            # a row without a pose stays as it is
+    start = table.copy()
+    tab = _t(table, device)
+    out, rms, nin, iters = ransac.refine_relative_pose(*(_t(p, device) for p in pts), tab, c_sq, n_valid=_t(n_valid, device),
+                                                       max_iters=10, want_stats=True)
+    assert out.data_ptr() == tab.data_ptr()
+    got, rms, nin, iters = tab.cpu().numpy(), rms.cpu().numpy(), nin.cpu().numpy(), iters.cpu().numpy()
+    assert np.array_equal(got[:, 12:], start[:, 12:])
+    for b in range(B):
+        nv = n_valid[b]
+        a = [pts[k, b, :nv] for k in range(4)]
+        Rr, tr, rrms, rnin, rit = refine_e.refine_relative_pose(start[b, :9].reshape(3, 3), start[b, 9:12], *a, c_sq, max_iters=10)
+        if b >= 4:
+            assert iters[b] == 0 == rit and np.array_equal(got[b], start[b])
+            continue
+        Rg, tg = got[b, :9].reshape(3, 3).astype(np.float64), got[b, 9:12].astype(np.float64)
+        assert geometry.rotation_angle_deg(Rg, Rr) < 1e-4 and geometry.direction_angle_deg(tg, tr) < 1e-3, b
+        assert abs(int(nin[b]) - rnin) <= 1 and abs(rms[b] - rrms) < 1e-5 * rrms and 0 < iters[b] <= 10
+        if nv >= 700:
+            R, t = truth[b]
+            assert geometry.rotation_angle_deg(Rg, R) < 0.15 and geometry.direction_angle_deg(tg, t) < 1.0
+
+
+def test_refine_relative_pose_mask_and_zero_iters(device):
+    from tests.test_refine_e import _scene, ransac_start
+    N = 1024
+    R, t, x1, x2, good = _scene(77, n=N)
+    c_sq = float(np.float32(9.0 * (1.0 / synthetic.FX) ** 2))
+    pts = [np.ascontiguousarray(a[None]) for a in (x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1])]
+    row = np.zeros((1, 12), np.float32)
+    R0, t0 = ransac_start(R, t, x1, x2, (1.0 / synthetic.FX) ** 2, 5)
+    row[0, :9] = R0.reshape(9); row[0, 9:] = t0
+    t = row[0, 9:].astype(np.float64)
+    sel = np.zeros(N, bool); sel[::2] = True
+    words = np.packbits(sel, bitorder="little").view(np.uint64).view(np.int64)[None]
+    tab = _t(row.copy(), device)
+    ransac.refine_relative_pose(*(_t(p, device) for p in pts), tab, c_sq, mask=_t(words, device), max_iters=8)
+    Rr, tr, *_ = refine_e.refine_relative_pose(R0, t, *(p[0] for p in pts), c_sq, valid=sel, max_iters=8)
+    g = tab.cpu().numpy()[0]
+    assert geometry.rotation_angle_deg(g[:9].reshape(3, 3).astype(np.float64), Rr) < 1e-4
+    tab0 = _t(row.copy(), device)
+    ransac.refine_relative_pose(*(_t(p, device) for p in pts), tab0, c_sq, max_iters=0)
+    assert np.array_equal(tab0.cpu().numpy(), row)
+
+
+def test_device_rodrigues_and_quaternion_pinned_by_scipy(device):
+    """ph_camera_from_pose's R block == SciPy's from_rotvec(r).as_matrix() transposed (cv2.Rodrigues, main.py:122) and
+    its quaternion == SciPy's, sign included (main.py:138-141); ph_project_points built on the same matrices."""
+    d = json.load(open(os.path.join(G, "rodrigues.json")))
+    rv = np.array([c["rvec"] for c in d["cases"]]); Rs = np.array([c["R"] for c in d["cases"]])
+    qs = np.array([c["quat_xyzw_of_Rt"] for c in d["cases"]])
+    tv = np.tile(np.array([0.05, -0.1, 0.9]), (len(rv), 1))
+    pose = np.concatenate([rv, tv], axis=1)
+    cam = {k: v.cpu().numpy() for k, v in board.camera_from_pose_batched(_t(pose, device)).items()}
+    for b in range(len(rv)):
+        assert np.abs(cam["R_cam_to_world"][b] - Rs[b].T).max() < 1e-14, rv[b]
+        want = qs[b][[3, 0, 1, 2]]
+        if branch_tie(Rs[b].T):         # sign hangs on the last bit of the matrix (tests/test_scipy_pins.py)
+            assert min(np.abs(cam["quaternion"][b] - want).max(), np.abs(cam["quaternion"][b] + want).max()) < 1e-12
+        else:
+            assert np.abs(cam["quaternion"][b] - want).max() < 1e-12, (rv[b], cam["quaternion"][b], qs[b])
+        assert np.abs(cam["position"][b] + Rs[b].T @ tv[b]).max() < 1e-14
+    # projection through SciPy's matrices (pinhole + the reference's distortion model, validate_pose.py:181-184)
+    obj = orc.board_object_points().reshape(-1, 3)[:64].astype(np.float32)
+    keep = [b for b in range(len(rv)) if np.all((obj.astype(np.float64) @ Rs[b].T + tv[b])[:, 2] > 0.3)]
+    objs = np.tile(obj[None], (len(keep), 1, 1))
+    uv, uvi = board.project_points_batched(_t(objs, device), _t(pose[keep], device))
+    uv, uvi = uv.cpu().numpy(), uvi.cpu().numpy()
+    assert len(keep) > 30
+    for k, b in enumerate(keep):
+        want = synthetic.distort_project(obj.astype(np.float64) @ Rs[b].T + tv[b])
+        assert np.abs(uv[k] - want).max() < 1e-8
+        assert np.array_equal(uvi[k], want.astype(np.int32)) or np.abs(want - np.round(want)).min() < 1e-6
