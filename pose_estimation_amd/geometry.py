@@ -33,11 +33,13 @@ def candidate_projections(E):
 
 
 def rotation_angle_deg(Ra, Rb):
-    c = (np.trace(Ra @ Rb.T) - 1) / 2
-    return float(np.degrees(np.arccos(np.clip(c, -1, 1))))
+    """Angle of Ra Rb' in degrees, as atan2(|antisymmetric part|, (trace - 1) / 2): arccos of the trace alone resolves
+    nothing below sqrt(eps) (0.02 degrees for matrices stored as float32)."""
+    D = np.asarray(Ra, np.float64) @ np.asarray(Rb, np.float64).T
+    s = 0.5 * np.sqrt((D[2, 1] - D[1, 2]) ** 2 + (D[0, 2] - D[2, 0]) ** 2 + (D[1, 0] - D[0, 1]) ** 2)
+    return float(np.degrees(np.arctan2(s, (np.trace(D) - 1) / 2)))
 
 
 def direction_angle_deg(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    c = np.dot(a, b) / (np.linalg.norm(a) * np.linalg.norm(b))
-    return float(np.degrees(np.arccos(np.clip(c, -1, 1))))
+    return float(np.degrees(np.arctan2(np.linalg.norm(np.cross(a, b)), np.dot(a, b))))

