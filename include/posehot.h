@@ -39,6 +39,7 @@ extern "C" {
 #define PH_ERR_UNSUPPORTED (-2) /* a size/dtype this build has no kernel for                    */
 #define PH_ERR_WORKSPACE (-3)   /* ws_bytes smaller than the matching *_ws_bytes() answer       */
 #define PH_ERR_LAUNCH (-4)      /* hipLaunch / hipMemsetAsync reported an error                 */
+#define PH_ERR_TOO_LARGE (-5)   /* beyond the static scratch of a no-allocation entry point     */
 
 /* Sentinels written for "no such neighbour" (empty / single-row train sets). */
 #define PH_NO_INDEX (-1)
@@ -157,6 +158,21 @@ size_t ph_solve_essential_5pt_ws_bytes(int B, int S);
 int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
                            const int32_t* samples, int B, int S, int N,
                            float* E, int32_t* n_solutions, void* ws, size_t ws_bytes, void* stream);
+
+/* The one entry point that ALLOCATES NOTHING and takes no workspace.  It has no counterpart in the reference; it is
+ * for callers that cannot call hipMalloc or bring a workspace: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same arguments, kernels and bit-identical outputs as ph_solve_essential_5pt; the
+ * polynomial records that call keeps in (ws, ws_bytes) live here in a file-scope __device__ array of the library,
+ * PH_NOALLOC_MAX_SAMPLES records = 5.7 MB, which every GPU the library runs on holds until the process ends (its
+ * address is looked up once per device, on the first call made with that device current — make that first call
+ * outside graph capture).  B * S > PH_NOALLOC_MAX_SAMPLES returns PH_ERR_TOO_LARGE and launches nothing.  Every call
+ * on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race on it — serialise
+ * them or use ph_solve_essential_5pt with separate workspaces.  Nothing in the array has to start at zero (every
+ * record a call reads, that call has written first), so the contents a previous call left behind do no harm. */
+#define PH_NOALLOC_MAX_SAMPLES 8192
+int ph_solve_essential_5pt_noalloc(const float* x1, const float* y1, const float* x2, const float* y2,
+                                   const int32_t* samples, int B, int S, int N,
+                                   float* E, int32_t* n_solutions, void* stream);
 
 /* P3P minimal solver (float64 inside, one thread per sample): absolute pose from three 3-D points and
  * their image points.  samples is [B][S][3] (indices into the item's N correspondences); (u, v) are

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ph_sample_minimal_keyed": (_i, [C.c_uint32, _p, _p, _i, _i, _i, _i, _p, _p]),
     "ph_solve_essential_5pt_ws_bytes": (_sz, [_i, _i]),
     "ph_solve_essential_5pt": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _sz, _p]),
+    "ph_solve_essential_5pt_noalloc": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "ph_gather_models": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "ph_decompose_essential": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ph_pose_table": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p]),

@@ -10,6 +10,7 @@ extern "C" const char* ph_status_string(int status) {
         case PH_ERR_UNSUPPORTED: return "unsupported size or dtype";
         case PH_ERR_WORKSPACE: return "workspace missing, misaligned or too small";
         case PH_ERR_LAUNCH: return "HIP launch failed";
+        case PH_ERR_TOO_LARGE: return "size exceeds the static scratch of the no-allocation entry point";
         default: return "unknown status";
     }
 }

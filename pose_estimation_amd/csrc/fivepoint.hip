@@ -11,6 +11,8 @@
 // slots are all-zero matrices, which score zero inliers).
 #include <math.h>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "fivepoint_core.hpp"
 
@@ -172,16 +174,10 @@ extern "C" size_t ph_solve_essential_5pt_ws_bytes(int B, int S) {
     return sizeof(ph5::Poly5) * (size_t)B * S;
 }
 
-extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
-                                      const int32_t* samples, int B, int S, int N, float* E, int32_t* n_solutions,
-                                      void* ws, size_t ws_bytes, void* stream) {
-    if (B < 0 || S < 0 || N < 0) return PH_ERR_INVALID_ARG;
-    if (B > 65535) return PH_ERR_UNSUPPORTED;
-    if (B == 0 || S == 0) return PH_OK;
-    if (!x1 || !y1 || !x2 || !y2 || !samples || !E) return PH_ERR_INVALID_ARG;
-    if (!ws || ws_bytes < ph_solve_essential_5pt_ws_bytes(B, S) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    ph5::Poly5* polys = (ph5::Poly5*)ws;
+namespace {
+
+int solve_5pt_launch(const float* x1, const float* y1, const float* x2, const float* y2, const int32_t* samples, int B, int S,
+                     int N, float* E, int32_t* n_solutions, ph5::Poly5* polys, hipStream_t st) {
     int threads = kPolyThreads;
     while (threads < kPolyThreadsMax && (long)B * ph_ceil_div(S, threads) > 256) threads += 4;
     const size_t lds = sizeof(ph5::Work5) * threads;           // up to 155 KB: above the 64 KiB default, opt in
@@ -194,4 +190,55 @@ extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const fl
     hipLaunchKernelGGL(fivepoint_roots_kernel, dim3((unsigned)((n_samples + 5) / 6)), dim3(64), 0, st, polys, n_samples, E,
                        n_solutions);
     return ph_launch_status();
+}
+
+// ---- the no-allocation variant's scratch: the polynomial records of PH_NOALLOC_MAX_SAMPLES minimal samples, in the
+// library's own device memory (every GPU the library runs on holds its copy of the array, at its own address, until
+// the process ends).  In host code the array's NAME is only a stand-in for the symbol: the device address is asked
+// for once per device with hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) unsigned char scratch[(size_t)PH_NOALLOC_MAX_SAMPLES * sizeof(ph5::Poly5)];
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices];            // per device, filled on the entry point's first call on that device
+std::mutex g_scratch_mu;
+
+int noalloc_scratch(ph5::Poly5** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return PH_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return PH_ERR_LAUNCH;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = (ph5::Poly5*)g_scratch_ptr[dev];
+    return PH_OK;
+}
+
+}  // namespace
+
+extern "C" int ph_solve_essential_5pt(const float* x1, const float* y1, const float* x2, const float* y2,
+                                      const int32_t* samples, int B, int S, int N, float* E, int32_t* n_solutions,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || S < 0 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || S == 0) return PH_OK;
+    if (!x1 || !y1 || !x2 || !y2 || !samples || !E) return PH_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < ph_solve_essential_5pt_ws_bytes(B, S) || !ph_aligned(ws, 8)) return PH_ERR_WORKSPACE;
+    return solve_5pt_launch(x1, y1, x2, y2, samples, B, S, N, E, n_solutions, (ph5::Poly5*)ws, (hipStream_t)stream);
+}
+
+extern "C" int ph_solve_essential_5pt_noalloc(const float* x1, const float* y1, const float* x2, const float* y2,
+                                              const int32_t* samples, int B, int S, int N, float* E, int32_t* n_solutions,
+                                              void* stream) {
+    if (B < 0 || S < 0 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if ((long)B * S > (long)PH_NOALLOC_MAX_SAMPLES) return PH_ERR_TOO_LARGE;     // beyond the static scratch: refuse, never spill
+    if (B == 0 || S == 0) return PH_OK;
+    if (!x1 || !y1 || !x2 || !y2 || !samples || !E) return PH_ERR_INVALID_ARG;
+    ph5::Poly5* polys = nullptr;
+    const int rc = noalloc_scratch(&polys);
+    if (rc != PH_OK) return rc;
+    // nothing in the scratch has to start at zero: the polynomial stage writes the record of every one of the B*S
+    // samples (failed ones as n = 0) before the roots stage reads it, on the same stream
+    return solve_5pt_launch(x1, y1, x2, y2, samples, B, S, N, E, n_solutions, polys, (hipStream_t)stream);
 }
