@@ -146,7 +146,7 @@ def main():
             "seconds": dt, "pairs_per_s": len(vi) / dt,
             "minimal_samples": args.samples, "hypothesis_slots": 10 * args.samples,
             "hypotheses": float(real.item()) / len(vi), "hyps_per_s": float(real.item()) / dt, "scoring": "bail-out",
-            "refine": "device LM on the Sampson error over the inliers" if not args.no_refine else "none",
+            "refine": "device LM, truncated Sampson cost (3 x threshold) over all matches" if not args.no_refine else "none",
             "gather": "one all_gather_into_tensor of the [pairs,16] pose table after the last chunk, inside the timed region",
             "scene_generation_s": gen_s}
     if rank != 0:
