@@ -106,7 +106,7 @@ def refine_relative_pose(R0, t0, x1, y1, x2, y2, c_sq, valid=None, max_iters=10)
         tn /= np.linalg.norm(tn)
         An, gn, cn, ssqn, ninn = _sums(Rn, tn, x1, y1, x2, y2, c_sq)
         if cn < cost:
-            done = (cost - cn) <= 1e-12 * max(cost, 1e-300) or float(d @ d) < 1e-26
+            done = (cost - cn) <= 1e-9 * max(cost, 1e-300) or float(d @ d) < 1e-20
             R, t, A, g, cost, ssq, nin = Rn, tn, An, gn, cn, ssqn, ninn
             lam = max(lam * 0.1, 1e-12)
             if done:

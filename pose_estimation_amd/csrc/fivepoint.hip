@@ -59,37 +59,282 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t seed, const uint32
     for (int k = 0; k < m; ++k) o[k] = got[k];
 }
 
-// Stage 1: one thread per minimal sample builds the degree-10 polynomial (sections 1-8 of the core).
-// Blocks are narrow on purpose: the work is a long dependent chain per sample over ~3 KB of dynamically
-// indexed working arrays, kept in LDS (one Work5 per thread), and with only B*S samples the launch is
-// latency-bound — narrow blocks spread the samples over all CUs.  32 threads per block while that gives at most
-// one block per CU; beyond, up to 52 (52 x 2984 B = 155 KB, the most one CU's LDS holds), so that e.g.
-// 32 pairs x 410 samples still run as ONE round of 256 blocks instead of two.
-constexpr int kPolyThreads = 32;
-constexpr int kPolyThreadsMax = 52;
+// Stage 1: TEN LANES per minimal sample build the degree-10 polynomial (sections 1-8 of the core), six samples per
+// one-wave block (lanes 60-63 idle) — the lane mapping of the roots stage.  The first version of this stage put one
+// thread on a sample and its 2.9 KB of dynamically indexed working arrays in LDS: 52 samples per CU, one wave per CU,
+// a dependent chain of ~3 000 LDS round trips — 411 us for 32 x 920 samples whose arithmetic is worth 4 us.  Here every
+// array lives in registers under static indices, or in 1.1 KB of LDS per sample where lanes must exchange data:
+//   P1  null space of the 5x9 epipolar system by Householder QR of its transpose (no pivoting, straight-line code;
+//       every lane runs it redundantly — in a wave that costs what one lane costs); lanes 0-3 then push one unit
+//       vector each through the reflections: an orthonormal basis X, Y, Z, W               -> LDS Ep, global basis
+//   P3  lanes 0-5: the six entries of EE' (degree 2); lanes 6-8: the three 2x2 minors of det E    -> LDS D[0..8]
+//   P4  lane l: coefficient l of trace(EE')                                                  -> LDS D[9]
+//   P5  lane l: constraint row l (0: det E = 0; 1 + 3r + c: entry (r, c) of 2EE'E - tr(EE')E = 0), four
+//       (degree 2) x (degree 1) products whose operands it reads from LDS                        -> registers A[20]
+//   P6  Gauss-Jordan on the 10 x 20 system, row per lane: per pivot column a group arg-max (partial pivoting over
+//       the rows not used yet; no swaps — a lane remembers which pivot it became) and a broadcast of the pivot
+//       row, both by ds_bpermute
+//   P7  rows e..j (pivots 4..9) -> LDS; lanes 0-2: rows k, l, m of B(z)                      -> LDS Bq, global
+//   P9  det B(z) (every lane, lane 0 stores) and the degree.
+// An orthonormal null-space basis other than the Gauss-Jordan + Gram-Schmidt one of the sequential core changes the
+// polynomial's coefficients, not the essential matrices it yields.
+namespace coop {
+
+constexpr int kGroup = 10, kGroupsPerWave = 6;
+struct alignas(16) SampleLds {
+    union {
+        double Ep[9][4];          // E entries as linear forms in (x, y, z, 1): Ep[e][k] = basis[k][e]   (P2 .. P5)
+        double Bq[3][14];         // rows of B(z): Bx (4) | By (4) | B1 (5) | pad                       (P8 .. P9)
+    };
+    double D[10][10];             // degree-2 polynomials (P3 .. P5), then the reduced rows by pivot index (P7 .. P8)
+};
+static_assert(sizeof(SampleLds) == 8 * (42 + 100), "layout");
+
+// operand tables, indexed by the lane within its group
+// P3: out = sum_t sgn * Ep[a] (x) Ep[b]  (degree 1 x degree 1)
+__device__ const int8_t kP3a[9][3] = {{0, 1, 2}, {0, 1, 2}, {0, 1, 2}, {3, 4, 5}, {3, 4, 5}, {6, 7, 8}, {1, 2, 0}, {2, 0, 0}, {0, 1, 0}};
+__device__ const int8_t kP3b[9][3] = {{0, 1, 2}, {3, 4, 5}, {6, 7, 8}, {3, 4, 5}, {6, 7, 8}, {6, 7, 8}, {5, 4, 0}, {3, 5, 0}, {4, 3, 0}};
+__device__ const int8_t kP3s[9][3] = {{1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, -1, 0}, {1, -1, 0}, {1, -1, 0}};
+// P5: row = sum_t sgn * D[d] (x) Ep[e]  (degree 2 x degree 1); D: 0..5 = EE' entries 00 01 02 11 12 22, 6..8 = minors, 9 = trace
+__device__ const int8_t kP5d[10][4] = {{6, 7, 8, 0}, {0, 1, 2, 9}, {0, 1, 2, 9}, {0, 1, 2, 9}, {1, 3, 4, 9}, {1, 3, 4, 9},
+                                       {1, 3, 4, 9}, {2, 4, 5, 9}, {2, 4, 5, 9}, {2, 4, 5, 9}};
+__device__ const int8_t kP5e[10][4] = {{6, 7, 8, 0}, {0, 3, 6, 0}, {1, 4, 7, 1}, {2, 5, 8, 2}, {0, 3, 6, 3}, {1, 4, 7, 4},
+                                       {2, 5, 8, 5}, {0, 3, 6, 6}, {1, 4, 7, 7}, {2, 5, 8, 8}};
+__device__ const int8_t kP5s[10][4] = {{1, 1, 1, 0}, {2, 2, 2, -1}, {2, 2, 2, -1}, {2, 2, 2, -1}, {2, 2, 2, -1}, {2, 2, 2, -1},
+                                       {2, 2, 2, -1}, {2, 2, 2, -1}, {2, 2, 2, -1}, {2, 2, 2, -1}};
+
+__device__ __forceinline__ void wave_sync() {              // LDS operations of one wave complete in order: compiler fence only
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace coop
+
 __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restrict__ x1, const float* __restrict__ y1,
-                                                                     const float* __restrict__ x2, const float* __restrict__ y2,
-                                                                     const int32_t* __restrict__ samples, int S, int N,
-                                                                     ph5::Poly5* __restrict__ polys) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    ph5::Work5* work = reinterpret_cast<ph5::Work5*>(smem);
-    const int b = blockIdx.y;
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    ph5::Poly5* out = polys + (size_t)b * S + s;
-    const int32_t* si = samples + ((size_t)b * S + s) * 5;
-    double pts[5][4];
+                                                            const float* __restrict__ x2, const float* __restrict__ y2,
+                                                            const int32_t* __restrict__ samples, long n_samples, int S, int N,
+                                                            ph5::Poly5* __restrict__ polys) {
+    using namespace coop;
+    __shared__ SampleLds lds[kGroupsPerWave];
+    const int lane = threadIdx.x;
+    const int g = min(lane / kGroup, kGroupsPerWave - 1), l = lane - kGroup * g;     // lanes 60-63 shadow group 5 (l >= 10)
+    const int base = kGroup * g;
+    const long s = (long)blockIdx.x * kGroupsPerWave + g;
+    const bool active = (lane < kGroup * kGroupsPerWave) && (s < n_samples);
+    const long sc = min(s, n_samples - 1);
+    const long b = sc / S;
+    SampleLds& L = lds[g];
+    ph5::Poly5* out = polys + sc;
+
+    // ---- P0: the five correspondences (every lane of the group loads them)
     bool ok = true;
+    double M[9][5];                                      // transpose of the epipolar system: column r = row q_r
+    {
+        const int32_t* si = samples + sc * 5;
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int i = si[r];
-        ok &= (i >= 0 && i < N);
-        const size_t o = (size_t)b * N + (ok ? i : 0);
-        pts[r][0] = x1[o]; pts[r][1] = y1[o]; pts[r][2] = x2[o]; pts[r][3] = y2[o];
+        for (int r = 0; r < 5; ++r) {
+            const int i = si[r];
+            ok &= (i >= 0 && i < N);
+            const size_t o = (size_t)b * N + (ok ? i : 0);
+            const double a = x1[o], c = y1[o], d = x2[o], e = y2[o];
+            M[0][r] = d * a; M[1][r] = d * c; M[2][r] = d; M[3][r] = e * a; M[4][r] = e * c; M[5][r] = e;
+            M[6][r] = a; M[7][r] = c; M[8][r] = 1.0;
+        }
     }
-    ph5::Poly5 P;
-    if (!ok || !ph5::build_polynomial(pts, P, work[threadIdx.x])) P.n = 0;
-    *out = P;
+    // ---- P1: Householder QR of M (9 x 5); reflector k is kept in place: v_k = M[k..8][k], H_k = I - beta_k v_k v_k'
+    double beta[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        double n2 = 0.0;
+#pragma unroll
+        for (int i = k; i < 9; ++i) n2 = fma(M[i][k], M[i][k], n2);
+        const double nrm = sqrt(n2);
+        ok &= nrm > 1e-12;                               // a column that is (numerically) dependent: degenerate sample
+        const double alpha = M[k][k] > 0.0 ? -nrm : nrm;
+        const double v0 = M[k][k] - alpha;
+        M[k][k] = v0;
+        const double vtv = fma(v0, v0, n2 - (v0 + alpha) * (v0 + alpha));     // |v|^2 = |x|^2 - x0^2 + v0^2
+        beta[k] = vtv > 0.0 ? 2.0 / vtv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < 5; ++j) {
+            double d = 0.0;
+#pragma unroll
+            for (int i = k; i < 9; ++i) d = fma(M[i][k], M[i][j], d);
+            d *= beta[k];
+#pragma unroll
+            for (int i = k; i < 9; ++i) M[i][j] = fma(-d, M[i][k], M[i][j]);
+        }
+    }
+    // ---- P2: null vector l (lanes 0-3) = H_0 H_1 ... H_4 e_{5+l}
+    {
+        double nv[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) nv[i] = (i == 5 + l) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 4; k >= 0; --k) {
+            double d = 0.0;
+#pragma unroll
+            for (int i = k; i < 9; ++i) d = fma(M[i][k], nv[i], d);
+            d *= beta[k];
+#pragma unroll
+            for (int i = k; i < 9; ++i) nv[i] = fma(-d, M[i][k], nv[i]);
+        }
+        if (l < 4) {
+#pragma unroll
+            for (int e = 0; e < 9; ++e) L.Ep[e][l] = nv[e];
+            if (active)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) out->basis[l][e] = nv[e];
+        }
+    }
+    wave_sync();
+    // ---- P3: lanes 0-8: three (degree 1) x (degree 1) products
+    if (l < 9) {
+        double acc[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const double sg = (double)kP3s[l][t];
+            const double2* ap = reinterpret_cast<const double2*>(L.Ep[kP3a[l][t]]);
+            const double2* bp = reinterpret_cast<const double2*>(L.Ep[kP3b[l][t]]);
+            const double2 a01 = ap[0], a23 = ap[1], b01 = bp[0], b23 = bp[1];
+            const double a[4] = {a01.x * sg, a01.y * sg, a23.x * sg, a23.y * sg}, bb[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[ph5::kMul11[i][j]] = fma(a[i], bb[j], acc[ph5::kMul11[i][j]]);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) L.D[l][k] = acc[k];
+    }
+    wave_sync();
+    // ---- P4: trace(EE'), coefficient l
+    if (l < 10) L.D[9][l] = L.D[0][l] + L.D[3][l] + L.D[5][l];
+    wave_sync();
+    // ---- P5: constraint row l, columns in Nister's order
+    double A[20];
+    {
+        const int lr = min(l, 9);
+        double tmp[20];
+#pragma unroll
+        for (int k = 0; k < 20; ++k) tmp[k] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double sg = (double)kP5s[lr][t];
+            const double* dp = L.D[kP5d[lr][t]];
+            const double2* ep = reinterpret_cast<const double2*>(L.Ep[kP5e[lr][t]]);
+            const double2 e01 = ep[0], e23 = ep[1];
+            const double e4[4] = {e01.x * sg, e01.y * sg, e23.x * sg, e23.y * sg};
+            double d10[10];
+#pragma unroll
+            for (int i = 0; i < 10; i += 2) { const double2 v = *reinterpret_cast<const double2*>(dp + i); d10[i] = v.x; d10[i + 1] = v.y; }
+#pragma unroll
+            for (int i = 0; i < 10; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tmp[ph5::kMul21[i][j]] = fma(d10[i], e4[j], tmp[ph5::kMul21[i][j]]);
+        }
+#pragma unroll
+        for (int c = 0; c < 20; ++c) A[c] = tmp[ph5::kNister[c]];
+    }
+    wave_sync();                                         // D and Ep are dead from here on (their storage is reused)
+    // ---- P6: Gauss-Jordan, row per lane
+    int piv = (l < 10) ? -1 : 99;                        // pivot index this lane's row became (-1: not yet); idle lanes never compete
+#pragma unroll
+    for (int c = 0; c < 10; ++c) {
+        const double v = piv < 0 ? fabs(A[c]) : -1.0;
+        double best = -1.0;
+        int p = 0;
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) {
+            const double vk = __shfl(v, base + k);
+            if (vk > best) { best = vk; p = k; }
+        }
+        ok &= best > 1e-14;
+        const bool me = (l == p);
+        if (me) {
+            const double inv = 1.0 / A[c];
+#pragma unroll
+            for (int j = c + 1; j < 20; ++j) A[j] *= inv;
+            piv = c;
+        }
+        const double f = A[c];
+#pragma unroll
+        for (int j = c + 1; j < 20; ++j) {
+            const double pr = __shfl(A[j], base + p);
+            A[j] = me ? A[j] : fma(-f, pr, A[j]);
+        }
+    }
+    // ---- P7: the right halves of rows e..j (pivots 4..9) -> LDS, by pivot index
+    if (piv >= 4 && piv < 10) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) L.D[piv][j] = A[10 + j];
+    }
+    wave_sync();
+    // ---- P8: k = e - z f, l = g - z h, m = i - z j (ascending powers of z)
+    if (l < 3) {
+        const double* p = L.D[4 + 2 * l];
+        const double* r = L.D[5 + 2 * l];
+        double q13[13];
+        q13[3] = -r[0]; q13[2] = p[0] - r[1]; q13[1] = p[1] - r[2]; q13[0] = p[2];
+        q13[7] = -r[3]; q13[6] = p[3] - r[4]; q13[5] = p[4] - r[5]; q13[4] = p[5];
+        q13[12] = -r[6]; q13[11] = p[6] - r[7]; q13[10] = p[7] - r[8]; q13[9] = p[8] - r[9]; q13[8] = p[9];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) L.Bq[l][k] = q13[k];
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { out->Bx[l][k] = q13[k]; out->By[l][k] = q13[4 + k]; }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) out->B1[l][k] = q13[8 + k];
+        }
+    }
+    wave_sync();
+    // ---- P9: det B(z), degree 10 (every lane; lane 0 of the group stores)
+    {
+        double Bx[3][4], By[3][4], B1[3][5], c[11];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { Bx[q][k] = L.Bq[q][k]; By[q][k] = L.Bq[q][4 + k]; }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) B1[q][k] = L.Bq[q][8 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) c[k] = 0.0;
+        double t7[8], t6[7];
+        auto pmul = [](const double* a, int na, const double* bb, int nb, double sgn, double* o) {
+#pragma unroll
+            for (int i = 0; i < na; ++i)
+#pragma unroll
+                for (int j = 0; j < nb; ++j) o[i + j] = fma(sgn * a[i], bb[j], o[i + j]);
+        };
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t7[k] = 0.0;
+        pmul(By[1], 4, B1[2], 5, 1.0, t7); pmul(B1[1], 5, By[2], 4, -1.0, t7);
+        pmul(Bx[0], 4, t7, 8, 1.0, c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t7[k] = 0.0;
+        pmul(Bx[1], 4, B1[2], 5, 1.0, t7); pmul(B1[1], 5, Bx[2], 4, -1.0, t7);
+        pmul(By[0], 4, t7, 8, -1.0, c);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) t6[k] = 0.0;
+        pmul(Bx[1], 4, By[2], 4, 1.0, t6); pmul(By[1], 4, Bx[2], 4, -1.0, t6);
+        pmul(B1[0], 5, t6, 7, 1.0, c);
+        double cmax = 0.0;
+#pragma unroll
+        for (int k = 0; k <= 10; ++k) cmax = fmax(cmax, fabs(c[k]));
+        ok = ok && (cmax > 0.0) && (cmax < HUGE_VAL);
+        int n = 10;
+#pragma unroll
+        for (int k = 10; k >= 1; --k)                     // a tiny leading coefficient is a legitimate huge root: keep it
+            if (n == k && fabs(c[k]) <= 1e-30 * cmax) n = k - 1;
+        if (!ok || n < 1) n = 0;
+        if (active && l == 0) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) out->c[k] = c[k];
+            out->n = n;
+        }
+    }
 }
 
 // Stage 2: one lane per (sample, root): 6 samples x 10 roots per wave (lanes 60-63 idle).  The ten lanes
@@ -178,15 +423,9 @@ namespace {
 
 int solve_5pt_launch(const float* x1, const float* y1, const float* x2, const float* y2, const int32_t* samples, int B, int S,
                      int N, float* E, int32_t* n_solutions, ph5::Poly5* polys, hipStream_t st) {
-    int threads = kPolyThreads;
-    while (threads < kPolyThreadsMax && (long)B * ph_ceil_div(S, threads) > 256) threads += 4;
-    const size_t lds = sizeof(ph5::Work5) * threads;           // up to 155 KB: above the 64 KiB default, opt in
-    if (hipFuncSetAttribute((const void*)fivepoint_poly_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(sizeof(ph5::Work5) * kPolyThreadsMax)) != hipSuccess)
-        return PH_ERR_LAUNCH;
-    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3(ph_ceil_div(S, threads), B), dim3(threads), lds, st, x1, y1, x2, y2,
-                       samples, S, N, polys);
     const long n_samples = (long)B * S;
+    hipLaunchKernelGGL(fivepoint_poly_kernel, dim3((unsigned)((n_samples + 5) / 6)), dim3(64), 0, st, x1, y1, x2, y2, samples,
+                       n_samples, S, N, polys);
     hipLaunchKernelGGL(fivepoint_roots_kernel, dim3((unsigned)((n_samples + 5) / 6)), dim3(64), 0, st, polys, n_samples, E,
                        n_solutions);
     return ph_launch_status();

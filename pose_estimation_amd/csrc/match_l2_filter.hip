@@ -120,11 +120,13 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
 // Train tile image, written once per (pair, staged tile) and streamed by every query block of the pair straight into
 // LDS (global_load_lds: no registers, no VALU, no LDS write instructions in the filter loop).  It is the LDS image:
 //   uint4 [0, kSub*512)          scaled fp16 rows, MFMA tile after MFMA tile; chunk p of row r at r*16 + (p ^ (r & 15))
-//   then kSub*kQT*32 floats      sq*st*(-|t|^2/2) of the 32 rows of every MFMA tile, kQT copies each (one per column
-//                                tile: a second LDS address instead of register copies); -inf for rows at or beyond
-//                                the pair's valid count
+//   then kSub*32 floats          sq*st*(-|t|^2/2) of the 32 rows of every MFMA tile (read ONCE per MFMA tile into 16
+//                                registers that are the C operand of the first MFMA of every column tile's chain: the
+//                                LDS pipe is the busiest unit of this kernel — at the MFMA peak a CU has time for one
+//                                ds_read_b128 per MFMA, and a copy of the presets per column tile was 0.5 of that);
+//                                -inf for rows at or beyond the pair's valid count
 constexpr int kImgRows = kSub * kTR * kCPR;               // uint4
-constexpr int kImgTail = kSub * kQT * kTR / 4;            // uint4
+constexpr int kImgTail = kSub * kTR / 4;                  // uint4
 constexpr int kImg = kImgRows + kImgTail;                 // uint4 per staged tile image
 __global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restrict__ dt, const float* __restrict__ tnorm,
                                                          const int32_t* __restrict__ view_t, const int32_t* __restrict__ n_t,
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restric
         const float4 c = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
         out[row * kCPR + (p ^ (row & 15))] = to_f16x8(a, c, sc.st);
     }
-    if (tid < kSub * kQT * kTR) {
-        const int sub = tid / (kQT * kTR), row = sub * kTR + (tid & (kTR - 1));
+    if (tid < kSub * kTR) {
+        const int sub = tid / kTR, row = sub * kTR + (tid & (kTR - 1));
         ((float*)(out + kImgRows))[tid] = (t0 + row < ntv) ? -0.5f * tnorm[(size_t)vt * nt + t0 + row] * sc.s : -INFINITY;
     }
 }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     const float* __restrict__ qnorm, const float* __restrict__ tqmax,
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
-    static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256, "staging deal");
+    static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256 && kSub * kTR <= 256, "staging deal");
     __shared__ uint4 smem[(kDepth + 1) * kImg];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
 
@@ -254,17 +256,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         const uint4* rh = smem + buf * kImg + sub * (kTR * kCPR) + li * kCPR;
 #pragma unroll
         for (int s = 0; s < kNS; ++s) af[s] = rh[(2 * s + h) ^ (li & 15)];
-        const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kQT * kTR / 4);
+        const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kTR / 4);
+        f32x16 preset;
 #pragma unroll
-        for (int ct = 0; ct < kQT; ++ct) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 z = tnl[ct * (kTR / 4) + 2 * g + h];      // rows 8g + 4h .. +3
-                acc[ct][4 * g + 0] = z.x; acc[ct][4 * g + 1] = z.y; acc[ct][4 * g + 2] = z.z; acc[ct][4 * g + 3] = z.w;
-            }
+        for (int g = 0; g < 4; ++g) {
+            const float4 z = tnl[2 * g + h];                           // rows 8g + 4h .. +3
+            preset[4 * g + 0] = z.x; preset[4 * g + 1] = z.y; preset[4 * g + 2] = z.z; preset[4 * g + 3] = z.w;
         }
 #pragma unroll
-        for (int s = 0; s < kNS; ++s) {
+        for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[0], bh[ct][0], preset);
+#pragma unroll
+        for (int s = 1; s < kNS; ++s) {
 #pragma unroll
             for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[s], bh[ct][s], acc[ct]);
         }

@@ -5,9 +5,9 @@
 //   minimise  sum_i min(r_i^2, c^2),  r_i = (x2' E x1) / sqrt((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2),
 //   E = [t]x R, |t| = 1: 5 degrees of freedom, R <- exp([dw]x) R, t <- normalise(t + d3 b1 + d4 b2).
 //
-// One 256-thread block per pair, float64.  A pass over the pair's correspondences (coalesced SoA loads, points on
+// One 512-thread block per pair, float64.  A pass over the pair's correspondences (coalesced SoA loads, points on
 // lanes) produces the normal equations of the correspondences inside the truncation (15 + 5 sums), their sum of
-// squares, their number and the number of valid correspondences; the sums are reduced by wave shuffles and a 4-row
+// squares, their number and the number of valid correspondences; the sums are reduced by wave shuffles and an 8-row
 // LDS table; thread 0 solves the damped 5x5 system (Cholesky, Marquardt scaling) and proposes the next pose, whose
 // pass is both its cost and — when it is accepted — the next normal equations: ONE pass per iteration.
 #include <math.h>
@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int kNT = 256;
+constexpr int kNT = 512;          // 8 waves: two per SIMD of one CU, up to 256 VGPRs each (the 5 derivative matrices stay in registers)
 constexpr int kNW = kNT / 64;
 constexpr int kSums = 23;          // 15 (J'J upper) + 5 (J'r) + ssq + n_inside + n_valid
 
@@ -102,7 +102,11 @@ __device__ __forceinline__ void pass(const double* Rsh, const double* tsh, const
         const double f0 = E[0] * a2 + E[3] * c2 + E[6], f1 = E[1] * a2 + E[4] * c2 + E[7];
         const double num = a2 * e0 + c2 * e1 + e2;
         const double den = fmax(e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1, 1e-300);
-        const double isq = 1.0 / sqrt(den);
+        // 1/sqrt(den): f32 estimate + two Newton steps (23 -> 46 -> 92 bits) instead of an f64 sqrt and an f64 division
+        double isq = (double)__builtin_amdgcn_rsqf((float)den);
+        isq = isq * (1.5 - 0.5 * den * isq * isq);
+        isq = isq * (1.5 - 0.5 * den * isq * isq);
+        const double iden = isq * isq;
         const double r = num * isq;
         acc[22] += 1.0;
         if (!(r * r < c_sq)) continue;
@@ -114,7 +118,7 @@ __device__ __forceinline__ void pass(const double* Rsh, const double* tsh, const
             const double h0 = g[0] * a2 + g[3] * c2 + g[6], h1 = g[1] * a2 + g[4] * c2 + g[7];
             const double dnum = a2 * g0 + c2 * g1 + g2;
             const double dden = 2.0 * (e0 * g0 + e1 * g1 + f0 * h0 + f1 * h1);
-            J[k] = dnum * isq - 0.5 * num * dden * isq / den;
+            J[k] = dnum * isq - 0.5 * num * dden * isq * iden;
         }
         int q = 0;
 #pragma unroll
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* 
                                                                    int32_t* __restrict__ iters_out) {
     __shared__ double red[kNW][kSums];
     __shared__ double sh_R[9], sh_t[3], sh_Rc[9], sh_tc[3];
-    __shared__ int sh_flag;                 // 0: trial pose ready, 1: stop, 2: no trial this iteration (system not p.d.)
+    __shared__ double sh_A[15], sh_g[5];    // normal equations at the accepted pose (thread 0's state, kept out of everybody's registers)
+    __shared__ int sh_stop;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
     const size_t o = (size_t)b * N;
@@ -154,104 +159,127 @@ __global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* 
         double t[3] = {(double)P[9], (double)P[10], (double)P[11]};
         const double nt = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
         bool ok = nt > 0.0 && nt < 1e300;                         // NaN fails both
-        for (int k = 0; k < 9; ++k) { sh_R[k] = (double)P[k]; ok = ok && fabs(sh_R[k]) <= 2.0; }
-        for (int k = 0; k < 3; ++k) sh_t[k] = ok ? t[k] / nt : 0.0;
-        sh_flag = ok ? 0 : 1;
+        for (int k = 0; k < 9; ++k) { sh_Rc[k] = (double)P[k]; ok = ok && fabs(sh_Rc[k]) <= 2.0; }
+        for (int k = 0; k < 3; ++k) sh_tc[k] = ok ? t[k] / nt : 0.0;
+        sh_stop = (ok && max_iters > 0) ? 0 : 1;
     }
     __syncthreads();
-    const bool usable = sh_flag == 0;
-    __syncthreads();
 
-    // thread 0's accepted state
-    double A[15], g[5], cost = 0.0, ssq = 0.0, nin = 0.0, lambda = 1e-3;
+    // thread 0's scalars
+    double cost = 0.0, ssq = 0.0, nin = 0.0, lambda = 1e-3, dd = 0.0;
     int it = 0;
-    if (usable) {
-        pass(sh_R, sh_t, x1, y1, x2, y2, mask, nv, c_sq, red);
+    bool first = true, moved = false;
+    // Every trip: one pass at the trial pose (the start pose on the first trip), then thread 0 accepts or rejects it and,
+    // unless the loop is over, solves the damped system for the next trial.
+    while (sh_stop == 0) {
+        __syncthreads();                                           // everybody has read sh_stop before thread 0 rewrites it
+        pass(sh_Rc, sh_tc, x1, y1, x2, y2, mask, nv, c_sq, red);
         if (tid == 0) {
             double s[kSums];
-            for (int k = 0; k < kSums; ++k) { s[k] = 0.0; for (int w = 0; w < kNW; ++w) s[k] += red[w][k]; }
-            for (int k = 0; k < 15; ++k) A[k] = s[k];
-            for (int k = 0; k < 5; ++k) g[k] = s[15 + k];
-            ssq = s[20]; nin = s[21];
-            cost = ssq + (s[22] - nin) * c_sq;
-            sh_flag = (s[22] < 6.0) ? 1 : 0;
-        }
-        __syncthreads();
-        for (; it < max_iters;) {
-            if (sh_flag == 1) break;                               // uniform: read after a barrier
-            ++it;
-            __syncthreads();                                       // everybody has read sh_flag before thread 0 rewrites it
-            if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < kSums; ++k) {
+                s[k] = 0.0;
+#pragma unroll
+                for (int w = 0; w < kNW; ++w) s[k] += red[w][k];
+            }
+            const double cn = s[20] + (s[22] - s[21]) * c_sq;
+            bool stop = false;
+            if (first || cn < cost) {
+                stop = !first && ((cost - cn) <= 1e-9 * fmax(cost, 1e-300) || dd < 1e-20);
+                moved = moved || !first;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) sh_A[k] = s[k];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sh_g[k] = s[15 + k];
+                ssq = s[20]; nin = s[21]; cost = cn;
+                for (int k = 0; k < 9; ++k) sh_R[k] = sh_Rc[k];
+                for (int k = 0; k < 3; ++k) sh_t[k] = sh_tc[k];
+                if (first) stop = s[22] < 6.0;
+                else lambda = fmax(lambda * 0.1, 1e-12);
+                first = false;
+            } else {
+                lambda *= 10.0;
+                stop = lambda > 1e12;
+            }
+            // next trial: solve (J'J + lambda diag(J'J)) d = -J'r; a system that is not positive definite costs an
+            // iteration and a decade of lambda, no pass
+            bool have = false;
+            while (!stop && !have && it < max_iters) {
+                ++it;
+                // every loop below is unrolled with constant indices: the small matrices stay in registers (dynamic
+                // indexing would put them in scratch memory, a round trip to the L2 per access of this serial part)
                 double M[5][5], L[5][5], d[5];
-                int q = 0;
-                for (int a = 0; a < 5; ++a)
-                    for (int c = a; c < 5; ++c) { M[a][c] = A[q]; M[c][a] = A[q]; ++q; }
+                {
+                    int q = 0;
+#pragma unroll
+                    for (int a = 0; a < 5; ++a)
+#pragma unroll
+                        for (int c = a; c < 5; ++c) { M[a][c] = sh_A[q]; M[c][a] = sh_A[q]; ++q; }
+                }
+#pragma unroll
                 for (int a = 0; a < 5; ++a) M[a][a] += lambda * M[a][a] + 1e-300;
                 bool ok = true;
-                for (int a = 0; a < 5 && ok; ++a)
+#pragma unroll
+                for (int a = 0; a < 5; ++a)
+#pragma unroll
                     for (int c = 0; c <= a; ++c) {
                         double v = M[a][c];
+#pragma unroll
                         for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
-                        if (a == c) { if (!(v > 0.0)) { ok = false; break; } L[a][a] = sqrt(v); }
+                        if (a == c) { ok = ok && (v > 0.0); L[a][a] = sqrt(fmax(v, 1e-300)); }
                         else L[a][c] = v / L[c][c];
                     }
                 if (!ok) {
                     lambda *= 10.0;
-                    sh_flag = lambda > 1e12 ? 1 : 2;
-                } else {
-                    for (int a = 0; a < 5; ++a) { double v = -g[a]; for (int k = 0; k < a; ++k) v -= L[a][k] * d[k]; d[a] = v / L[a][a]; }
-                    for (int a = 4; a >= 0; --a) { double v = d[a]; for (int k = a + 1; k < 5; ++k) v -= L[k][a] * d[k]; d[a] = v / L[a][a]; }
-                    double dR[9], Rcur[9], b1[3], b2[3], tcur[3];
-                    exp_so3(d, dR);
-                    for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
-                    for (int k = 0; k < 3; ++k) tcur[k] = sh_t[k];
-                    for (int r = 0; r < 3; ++r)
-                        for (int c = 0; c < 3; ++c)
-                            sh_Rc[3 * r + c] = dR[3 * r] * Rcur[c] + dR[3 * r + 1] * Rcur[3 + c] + dR[3 * r + 2] * Rcur[6 + c];
-                    tangent_basis(tcur, b1, b2);
-                    double tn[3], n2 = 0.0;
-                    for (int k = 0; k < 3; ++k) { tn[k] = tcur[k] + d[3] * b1[k] + d[4] * b2[k]; n2 += tn[k] * tn[k]; }
-                    const double inv = 1.0 / sqrt(n2);
-                    for (int k = 0; k < 3; ++k) sh_tc[k] = tn[k] * inv;
-                    double dd = 0.0;
-                    for (int a = 0; a < 5; ++a) dd += d[a] * d[a];
-                    red[0][0] = dd;                                // handed to the accept step below (thread 0 only)
-                    sh_flag = 0;
+                    stop = lambda > 1e12;
+                    continue;
                 }
-            }
-            __syncthreads();
-            const int flag = sh_flag;
-            if (flag != 0) continue;                               // 1: the loop head stops; 2: next iteration re-solves
-            double dd = 0.0;
-            if (tid == 0) dd = red[0][0];
-            __syncthreads();
-            pass(sh_Rc, sh_tc, x1, y1, x2, y2, mask, nv, c_sq, red);
-            if (tid == 0) {
-                double s[kSums];
-                for (int k = 0; k < kSums; ++k) { s[k] = 0.0; for (int w = 0; w < kNW; ++w) s[k] += red[w][k]; }
-                const double cn = s[20] + (s[22] - s[21]) * c_sq;
-                if (cn < cost) {
-                    const bool done = (cost - cn) <= 1e-12 * fmax(cost, 1e-300) || dd < 1e-26;
-                    for (int k = 0; k < 15; ++k) A[k] = s[k];
-                    for (int k = 0; k < 5; ++k) g[k] = s[15 + k];
-                    ssq = s[20]; nin = s[21]; cost = cn;
-                    for (int k = 0; k < 9; ++k) sh_R[k] = sh_Rc[k];
-                    for (int k = 0; k < 3; ++k) sh_t[k] = sh_tc[k];
-                    lambda = fmax(lambda * 0.1, 1e-12);
-                    sh_flag = done ? 1 : 0;
-                } else {
-                    lambda *= 10.0;
-                    sh_flag = lambda > 1e12 ? 1 : 0;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) {
+                    double v = -sh_g[a];
+#pragma unroll
+                    for (int k = 0; k < a; ++k) v -= L[a][k] * d[k];
+                    d[a] = v / L[a][a];
                 }
+#pragma unroll
+                for (int a = 4; a >= 0; --a) {
+                    double v = d[a];
+#pragma unroll
+                    for (int k = a + 1; k < 5; ++k) v -= L[k][a] * d[k];
+                    d[a] = v / L[a][a];
+                }
+                double dR[9], Rcur[9], b1[3], b2[3], tcur[3];
+                exp_so3(d, dR);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tcur[k] = sh_t[k];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        sh_Rc[3 * r + c] = dR[3 * r] * Rcur[c] + dR[3 * r + 1] * Rcur[3 + c] + dR[3 * r + 2] * Rcur[6 + c];
+                tangent_basis(tcur, b1, b2);
+                double tn[3], n2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { tn[k] = tcur[k] + d[3] * b1[k] + d[4] * b2[k]; n2 += tn[k] * tn[k]; }
+                const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sh_tc[k] = tn[k] * inv;
+                dd = 0.0;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) dd += d[a] * d[a];
+                have = true;
             }
-            __syncthreads();
+            sh_stop = have ? 0 : 1;
         }
+        __syncthreads();
     }
     if (tid == 0) {
-        if (it > 0)                                                // no iteration ran: the caller's row stays bit for bit
+        if (moved) {                                               // no step accepted: the caller's row stays bit for bit
             for (int k = 0; k < 9; ++k) P[k] = (float)sh_R[k];
-        if (it > 0)
             for (int k = 0; k < 3; ++k) P[9 + k] = (float)sh_t[k];
+        }
         if (rms) rms[b] = nin > 0.0 ? sqrt(ssq / nin) : 0.0;
         if (n_inl) n_inl[b] = (int32_t)nin;
         if (iters_out) iters_out[b] = it;
