@@ -349,14 +349,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     const long s = (long)blockIdx.x * 6 + g;
     const bool active = (g < 6) && (s < n_samples);
     const ph5::Poly5* Pp = polys + (active ? s : 0);
-    ph5::Poly5 P;
-    for (int q = 0; q < 11; ++q) P.c[q] = Pp->c[q];
-    P.n = Pp->n;
-    const int n = P.n;
+    const int n = Pp->n;
+    double c[11];                                          // the polynomial in registers, zero above its degree
+#pragma unroll
+    for (int q = 0; q < 11; ++q) c[q] = (q <= n) ? Pp->c[q] : 0.0;
     const bool live = active && k < n;
-    ph5::cplx z = live ? ph5::aberth_start(P, k) : ph5::cplx{0.0, 0.0};
+    ph5::cplx z = live ? ph5::aberth_start10(c, n, k) : ph5::cplx{0.0, 0.0};
     for (int it = 0; it < ph5::kAberthMaxIter; ++it) {
         ph5::cplx sum = {0.0, 0.0};
+#pragma unroll
         for (int d = 1; d < 10; ++d) {
             int kk = k + d; kk = kk >= 10 ? kk - 10 : kk;
             const int src = min(10 * g + kk, 63);
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
         }
         double change = 0.0;
         if (live) {
-            const ph5::cplx w = ph5::aberth_step(P, z, sum);
+            const ph5::cplx w = ph5::aberth_step10(c, z, sum);
             z.re -= w.re; z.im -= w.im;
             change = (fabs(w.re) + fabs(w.im)) / (fabs(z.re) + fabs(z.im) + 1e-30);
         }
@@ -377,15 +378,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     }
     float e9[9];
     bool real = false;
-    if (live) {
-        for (int q = 0; q < 3; ++q) {
-            for (int r = 0; r < 4; ++r) { P.Bx[q][r] = Pp->Bx[q][r]; P.By[q][r] = Pp->By[q][r]; }
-            for (int r = 0; r < 5; ++r) P.B1[q][r] = Pp->B1[q][r];
-        }
-        for (int q = 0; q < 4; ++q)
-            for (int r = 0; r < 9; ++r) P.basis[q][r] = Pp->basis[q][r];
-        real = ph5::root_to_E(P, z, e9);
-    }
+    if (live) real = ph5::root_to_E10(c, *Pp, z, e9);
     if (active) {
         float* eo = E_out + (size_t)s * 90 + 9 * k;
         for (int e = 0; e < 9; ++e) eo[e] = real ? e9[e] : 0.0f;

@@ -301,6 +301,85 @@ PH_HD inline bool root_to_E(const Poly5& P, cplx z, float* e9) {
     return true;
 }
 
+// ---- fixed-length forms for the device's root stage: the coefficients above the degree are ZERO (c[k] = 0 for k > n),
+// so every Horner loop runs the full length 10 under constant indices and the polynomial stays in registers (a loop that
+// starts at the runtime degree indexes c[] dynamically, which puts it in scratch memory: one L2 round trip per Horner step).
+// A leading zero contributes exact zeros, so the values are those of the loops that start at n.
+PH_HD inline double lead_coeff(const double (&c)[11], int n) {
+    double l = c[0];
+#pragma unroll
+    for (int k = 1; k <= 10; ++k) l = (k == n) ? c[k] : l;
+    return l;
+}
+PH_HD inline cplx aberth_start10(const double (&c)[11], int n, int k) {
+    double rad = pow(fabs(c[0] / lead_coeff(c, n)) + 1e-300, 1.0 / n);
+    rad = fmin(fmax(rad, 1e-3), 1e3);
+    const double a = 6.283185307179586 * k / n + 0.4;
+    return {rad * cos(a), rad * sin(a)};
+}
+PH_HD inline cplx aberth_step10(const double (&c)[11], cplx zk, cplx sum) {
+    cplx p = {c[10], 0.0}, dp = {0.0, 0.0};
+#pragma unroll
+    for (int j = 9; j >= 0; --j) {
+        dp = cmul(dp, zk); dp.re += p.re; dp.im += p.im;
+        p = cmul(p, zk); p.re += c[j];
+    }
+    if (p.re == 0.0 && p.im == 0.0) return {0.0, 0.0};
+    const cplx nw = cdiv(p, dp);                          // Newton step
+    const cplx den = {1.0 - (nw.re * sum.re - nw.im * sum.im), -(nw.re * sum.im + nw.im * sum.re)};
+    const cplx w = cdiv(nw, den);
+    if (w.re == w.re && w.im == w.im) return w;
+    return {0.0, 0.0};
+}
+// root_to_E with the polynomial in registers and the rest of the record read where it lies (constant indices)
+PH_HD inline bool root_to_E10(const double (&c)[11], const Poly5& P, cplx z, float* e9) {
+    if (!(fabs(z.im) < 1e-6 * fmax(1.0, fabs(z.re)))) return false;
+    double zr = z.re;
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {                       // polish on the real axis
+        double p = c[10], dp = 0.0;
+#pragma unroll
+        for (int j = 9; j >= 0; --j) { dp = dp * zr + p; p = p * zr + c[j]; }
+        if (dp != 0.0) zr -= p / dp;
+    }
+    {   // a complex pair with a tiny imaginary part is not a solution: require p(zr) = 0 to rounding
+        double p = c[10], mag = fabs(c[10]);
+        const double az = fabs(zr);
+#pragma unroll
+        for (int j = 9; j >= 0; --j) { p = p * zr + c[j]; mag = mag * az + fabs(c[j]); }
+        if (!(fabs(p) <= 1e-10 * mag)) return false;
+    }
+    double Bz[3][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        Bz[q][0] = ((P.Bx[q][3] * zr + P.Bx[q][2]) * zr + P.Bx[q][1]) * zr + P.Bx[q][0];
+        Bz[q][1] = ((P.By[q][3] * zr + P.By[q][2]) * zr + P.By[q][1]) * zr + P.By[q][0];
+        Bz[q][2] = (((P.B1[q][4] * zr + P.B1[q][3]) * zr + P.B1[q][2]) * zr + P.B1[q][1]) * zr + P.B1[q][0];
+    }
+    double v0 = 0, v1 = 0, v2 = 0, vbest = -1.0;           // null vector = largest cross product of two rows
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double* a = Bz[q];
+        const double* d = Bz[(q + 1) % 3];
+        const double w0 = a[1] * d[2] - a[2] * d[1], w1 = a[2] * d[0] - a[0] * d[2], w2 = a[0] * d[1] - a[1] * d[0];
+        const double nn = w0 * w0 + w1 * w1 + w2 * w2;
+        if (nn > vbest) { vbest = nn; v0 = w0; v1 = w1; v2 = w2; }
+    }
+    if (!(fabs(v2) > 1e-14 * sqrt(vbest))) return false;
+    const double xr = v0 / v2, yr = v1 / v2;
+    double E[9], n2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) {
+        E[e] = xr * P.basis[0][e] + yr * P.basis[1][e] + zr * P.basis[2][e] + P.basis[3][e];
+        n2 += E[e] * E[e];
+    }
+    if (!(n2 > 0.0) || !(n2 < HUGE_VAL)) return false;
+    const double inv = 1.0 / sqrt(n2);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) e9[e] = (float)(E[e] * inv);
+    return true;
+}
+
 // Sequential reference of the whole solver (host debug harness; the device splits it over two kernels).
 // eo = 90 floats (10 slots, slot k = root k), pre-zeroed by the caller.  Returns the number of real solutions.
 PH_HD inline int solve_fivepoint(const double (&pts)[5][4], float* eo) {
