@@ -115,10 +115,100 @@ def board():
     np.savez_compressed(os.path.join(HERE, "board.npz"), **out)
 
 
+STDOUT_SEED = 21         # seed of the synthetic ring behind the stdout goldens (chosen by `best_stdout_seed`)
+
+
+def stdout_texts(seed=None, write=True):
+    """Expected stdout of `main.py --detections D` and `validate_pose.py --detections D` for the synthetic 8-camera
+    detections file (SURVEY.md §8d cfg 1 substitute: `synthetic.board_views(8)`), written line by line from the
+    reference's own print formats — /root/reference/main.py:159,165,184,198-199,441-463,468-484,509,431,512 and
+    /root/reference/validate_pose.py:303-305,314,333,339,357,374-375,391-407 — with the numbers from the CPU path
+    (host homography initial pose -> the oracle's NumPy Levenberg-Marquardt -> the oracle's SciPy-pinned camera
+    inversion / reprojection statistics), NOT from the GPU library: the GPU test compares the entry points' whole
+    stdout against these files byte for byte.  `{HTML}` stands for the scene file's path.
+    Lines the reference prints and this build does not: the per-image overlay files ("  💾 Saved: ...",
+    validate_pose.py:387) and the closing two lines about them (validate_pose.py:409-410) — drawing is out of scope."""
+    from pose_estimation_amd import board as bd
+    views = synthetic.board_views(8, seed=STDOUT_SEED if seed is None else seed)
+    _, board = bd.create_aruco_board()
+    W = (bd.MARKERS_X * bd.MARKER_LENGTH_MM + (bd.MARKERS_X - 1) * bd.MARKER_SEPARATION_MM) / 1000.0
+    H = (bd.MARKERS_Y * bd.MARKER_LENGTH_MM + (bd.MARKERS_Y - 1) * bd.MARKER_SEPARATION_MM) / 1000.0
+    worst = [1.0]
+
+    def margin(x, digits):       # distance of x from a rounding boundary at `digits` decimals, in units of the last digit
+        f = abs(x) * 10 ** digits
+        worst[0] = min(worst[0], abs((f % 1.0) - 0.5))
+
+    rec = []
+    for v in views:
+        obj, img = board.matchImagePoints(v["corners"], v["ids"])
+        obj, img = obj.reshape(-1, 3).astype(np.float64), img.reshape(-1, 2).astype(np.float64)
+        p0 = bd.initial_board_pose(obj, img, bd.CAMERA_MATRIX, bd.DIST_COEFFS)
+        pose, _ = orc.refine_pose_lm_np(obj, img, p0, max_iters=100)
+        pos, fwd, up, Rcw, q = orc.camera_position_and_orientation(pose[:3], pose[3:])
+        err, st = orc.reprojection_error(obj.astype(np.float32), img.astype(np.float32), pose[:3], pose[3:], orc.K4, orc.DIST_COEFFS)
+        rec.append(dict(filename=v["filename"], ids=v["ids"], pos=pos, q=q, n=len(v["ids"]), st=st))
+        for x in pos: margin(x, 3)
+        for x in q: margin(x, 4)
+        for k in ("mean", "max", "std"): margin(st[k], 2)
+    m = ["=" * 80, "🎯 ArUco Board Camera Pose Estimation", "=" * 80, "", "📋 Board Configuration:",
+         f"  - Grid: {bd.MARKERS_X} × {bd.MARKERS_Y} markers", f"  - Marker size: {bd.MARKER_LENGTH_MM} mm",
+         f"  - Separation: {bd.MARKER_SEPARATION_MM} mm", f"  - Total size: {W*1000:.1f} × {H*1000:.1f} mm",
+         "  - Dictionary: DICT_6X6_250", f"📷 Found {len(rec)} images"]
+    for r in rec:
+        m += ["", f"🔍 Processing: {r['filename']}", f"  ✓ Detected {r['n']} markers: {r['ids'].flatten().tolist()}",
+              f"  ✓ Camera position: [{r['pos'][0]:.3f}, {r['pos'][1]:.3f}, {r['pos'][2]:.3f}] m",
+              f"  ✓ Quaternion (w,x,y,z): [{r['q'][0]:.4f}, {r['q'][1]:.4f}, {r['q'][2]:.4f}, {r['q'][3]:.4f}]"]
+    m += ["", "=" * 100, "📊 CAMERA POSE SUMMARY", "=" * 100,
+          f"{'Image':<25} {'#':>4} {'X(m)':>8} {'Y(m)':>8} {'Z(m)':>8} │ {'qw':>7} {'qx':>7} {'qy':>7} {'qz':>7}", "-" * 100]
+    for r in rec:
+        pos, q = r["pos"], r["q"]
+        m.append(f"{r['filename']:<25} {r['n']:>4} {pos[0]:>8.3f} {pos[1]:>8.3f} {pos[2]:>8.3f} │ {q[0]:>7.4f} {q[1]:>7.4f} {q[2]:>7.4f} {q[3]:>7.4f}")
+    m += ["-" * 100, "", "📐 RELATIVE DISTANCES BETWEEN CAMERAS (meters):", "-" * 80]
+    for i in range(len(rec)):
+        for j in range(i + 1, len(rec)):
+            d = np.linalg.norm(rec[i]["pos"] - rec[j]["pos"])
+            margin(d, 3)
+            m.append(f"  Cam {i+1} ↔ Cam {j+1}: {d:.3f} m")
+    m += ["", "🎨 Creating interactive 3D visualization...", "", "✅ Interactive 3D visualization saved to: {HTML}", "", "✅ Done!"]
+    if write:
+        open(os.path.join(HERE, "main_stdout.txt"), "w", encoding="utf-8").write("\n".join(m) + "\n")
+
+    v_ = ["=" * 80, "🔍 Pose Estimation Validation", "=" * 80, "", f"📋 Board: {W*1000:.1f} × {H*1000:.1f} mm",
+          f"📷 Found {len(rec)} images", ""]
+    means = []
+    for r in rec:
+        st = r["st"]
+        v_ += [f"🔍 Validating: {r['filename']}", f"  ✓ Detected {r['n']} markers",
+               f"  📊 Reprojection Error: mean={st['mean']:.2f}px, max={st['max']:.2f}px, std={st['std']:.2f}px"]
+        means.append(st["mean"])
+    for x in (np.mean(means), np.max(means), np.min(means), np.std(means)): margin(x, 2)
+    grade = orc.summary_of_means(means)["grade"]
+    assert grade == "EXCELLENT"
+    v_ += ["", "=" * 80, "📊 VALIDATION SUMMARY", "=" * 80, f"  Mean reprojection error: {np.mean(means):.2f} pixels",
+           f"  Max reprojection error:  {np.max(means):.2f} pixels", f"  Min reprojection error:  {np.min(means):.2f} pixels",
+           f"  Std deviation:           {np.std(means):.2f} pixels", "-" * 80,
+           "  ✅ EXCELLENT: Mean error < 1 pixel - Pose estimation is very accurate!"]
+    if write:
+        open(os.path.join(HERE, "validate_stdout.txt"), "w", encoding="utf-8").write("\n".join(v_) + "\n")
+    else:
+        return worst[0]
+    # every printed number sits at least this far (in units of its last printed digit) from a rounding boundary: the GPU
+    # path agrees with the CPU path to ~1e-6 of a unit, so the texts are stable
+    print(f"stdout goldens: smallest distance of a printed number from a rounding boundary = {worst[0]:.4f} last-digit units")
+    assert worst[0] > 5e-3, "a printed value sits on a rounding boundary: run best_stdout_seed and change STDOUT_SEED"
+
+
+def best_stdout_seed():
+    """Seed (of the first 40) whose printed numbers stay farthest from a rounding boundary."""
+    best = max(range(1, 41), key=lambda sd: stdout_texts(seed=sd, write=False))
+    print("best seed", best, "margin", stdout_texts(seed=best, write=False))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # regenerate only the named fixtures, e.g. `make_golden.py rodrigues`
         for name in sys.argv[1:]:
             globals()[name]()
     else:
-        quaternions(); rodrigues(); matching(); scoring(); board()
+        quaternions(); rodrigues(); matching(); scoring(); board(); stdout_texts()
     print("golden fixtures written to", HERE)

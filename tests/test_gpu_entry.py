@@ -11,6 +11,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def test_entry_points_stdout_equals_golden_text(device, tmp_path):
+    """a-7 byte compatibility: the whole stdout of both entry points on the synthetic 8-camera detections file equals
+    tests/golden/{main,validate}_stdout.txt — texts written from the reference's print formats with numbers from the
+    CPU path (tests/golden/make_golden.py::stdout_texts), independent of the GPU library."""
+    sys.path.insert(0, ROOT)
+    import main as main_mod
+    import validate_pose as val_mod
+    from pose_estimation_amd import entry, synthetic
+    from tests.golden.make_golden import STDOUT_SEED
+    det_file, html = str(tmp_path / "dets.npz"), str(tmp_path / "scene" / "camera_poses_3d.html")
+    entry.save_detections(det_file, synthetic.board_views(8, seed=STDOUT_SEED))
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        main_mod.main(["--detections", det_file, "--output-html", html])
+    want = open(os.path.join(ROOT, "tests", "golden", "main_stdout.txt"), encoding="utf-8").read().replace("{HTML}", html)
+    assert buf.getvalue() == want
+    assert os.path.getsize(html) > 10000 and "Cam 8" in open(html, encoding="utf-8").read()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        val_mod.validate_all_images(detections=det_file)
+    assert buf.getvalue() == open(os.path.join(ROOT, "tests", "golden", "validate_stdout.txt"), encoding="utf-8").read()
+
+
 def test_main_and_validate_on_synthetic_ring(device, tmp_path):
     sys.path.insert(0, ROOT)
     import main as main_mod
@@ -21,7 +44,7 @@ def test_main_and_validate_on_synthetic_ring(device, tmp_path):
     entry.save_detections(det_file, views)
     buf = io.StringIO()
     with redirect_stdout(buf):
-        results = main_mod.main(["--detections", det_file])
+        results = main_mod.main(["--detections", det_file, "--output-html", str(tmp_path / "scene.html")])
     out = buf.getvalue()
     assert len(results) == 8 and set(results[0]) == {'filename', 'image_path', 'corners', 'ids', 'rvec', 'tvec',
                                                      'camera_position', 'camera_forward', 'camera_up', 'R_cam',

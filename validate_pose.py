@@ -39,7 +39,8 @@ def validate_all_images(image_folder=None, output_folder=None, rotate_to_portrai
     if not dets:
         print(f"❌ No images found in {image_folder}")
         return None
-    print(f"📷 Found {len(dets)} images  [{source}]\n")
+    print(f"[detections: {source}]", file=sys.stderr)
+    print(f"📷 Found {len(dets)} images\n")
 
     results = entry.process_detections(dets, board, bd.CAMERA_MATRIX, bd.DIST_COEFFS, verbose=False)
     by_name = {r['filename']: r for r in results}
