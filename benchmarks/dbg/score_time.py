@@ -1,0 +1,35 @@
+"""Exhaustive vs bail-out scoring time at the bench's shape (hypotheses generated from the pairs' own matches)."""
+import sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+from pose_estimation_amd import matching, ransac, synthetic
+dev = torch.device("cuda:0")
+P, S = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 920
+scs = [synthetic.two_view_pair(n=8192, seed=1002 + p) for p in range(min(P, 8))]
+t = lambda k: torch.from_numpy(np.stack([scs[p % len(scs)][k] for p in range(P)])).to(dev)
+dq, dt, kq, kt = t("desc1"), t("desc2"), t("kp1"), t("kp2")
+idx, d1, d2 = matching.match_l2(dq, dt)
+keep = matching.ratio_filter_l2(idx, d1, d2, 0.75)
+m = matching.compact_matches(idx, keep, kq, kt, want_indices=False)
+pts = (m["x1"], m["y1"], m["x2"], m["y2"])
+samples = ransac.sample_minimal(1000, m["n_match"], 8192, S)
+E, ns = ransac.solve_essential_5pt(*pts, samples, want_counts=True)
+thr_sq = float(np.float32((1.0 / synthetic.FX) ** 2))
+print("matches", m["n_match"].float().mean().item(), "real models", ns.sum(1).float().mean().item())
+def timeit(f, n=6):
+    ts = []
+    for _ in range(n):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record(); r = f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b) * 1e3)
+    return float(np.mean(ts[1:])), r
+te, ce = timeit(lambda: ransac.score_essential(E, *pts, thr_sq, m["n_match"], bailout=False))
+tb, cb = timeit(lambda: ransac.score_essential(E, *pts, thr_sq, m["n_match"], bailout=True))
+live = (E.abs().sum(2) > 0)
+work_full = (live.sum(1).float() * m["n_match"].float()).sum().item()
+print(f"exhaustive {te:.1f} us, bail-out {tb:.1f} us; live (hyp,point) tests {work_full:.3e}; exhaustive rate {work_full*20/te*1e6/7.86e13:.3f} of nominal VALU")
+print("best counts equal:", bool((ce.max(1).values == cb.max(1).values).all()), "mean best", ce.max(1).values.float().mean().item())
+# how much of the work a perfect bail-out (known = final best from the start) would do
+cnt = ce.float(); best = cnt.max(1, keepdim=True).values; N = m["n_match"].float()[:, None]
+p = cnt / N
+frac = torch.clamp((N - best) / (N - cnt).clamp(min=1), max=1.0)     # points seen before cnt + remaining < best (uniform inlier density)
+print("ideal bail-out work fraction", float((frac * live).sum() / live.sum()))

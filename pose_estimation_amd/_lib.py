@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libposehot.so")
+LIB_PATH = os.environ.get("POSEHOT_LIB") or os.path.join(_HERE, "libposehot.so")   # POSEHOT_LIB: another build of the same ABI (experiments)
 
 PH_OK = 0
 PH_NO_INDEX = -1
