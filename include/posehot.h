@@ -81,7 +81,10 @@ int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float* out, void*
  *   PH_PRECISION_F16_RERANK    one fp16 MFMA product per score (rows scaled per pair by powers of two) selects
  *                              ~11 candidate rows per query inside a proven error band, the contract's f32
  *                              chain re-ranks them (dim 128; dim 64 runs the f32 kernel).  Needs workspace.
- * d1sq/d2sq = squared distances of the best / second-best train row (+inf when absent). */
+ * d1sq/d2sq = squared distances of the best / second-best train row (+inf when absent).
+ * Descriptors must be finite.  A NaN or infinite element makes the neighbours of the queries and train rows it touches
+ * unspecified (they may come back as PH_NO_INDEX, and the two algorithms may then differ): comparisons with NaN are
+ * false, so such rows are simply never preferred — no launch fails and nothing is read or written out of bounds. */
 #define PH_PRECISION_F32 0
 #define PH_PRECISION_F16_RERANK 1
 size_t ph_match_l2_ws_bytes(int B, int nq, int nt, int dim, int precision);

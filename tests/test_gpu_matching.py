@@ -278,3 +278,27 @@ def test_l2_empty_train(device, precision):
     assert (idx == L.PH_NO_INDEX).all() and torch.isinf(d1).all() and torch.isinf(d2).all()
     keep = matching.ratio_filter_l2(idx, d1, d2, 0.75)
     assert int(keep.sum()) == 0
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_l2_nan_rows_are_never_preferred_and_nothing_faults(device, precision):
+    """posehot.h: descriptors must be finite; a NaN row makes only the neighbours it touches unspecified — the launch
+    completes, clean queries never pick the NaN train row, and those whose clean top-2 did not involve it keep their result."""
+    rng = np.random.default_rng(5)
+    q = synthetic.sift_like(rng, 700, 128); t = synthetic.sift_like(rng, 900, 128)
+    tq, tt = torch.from_numpy(q[None]).to(device), torch.from_numpy(t[None]).to(device)
+    idx0, a0, b0 = (x.cpu().numpy()[0] for x in matching.match_l2(tq, tt, precision=precision))
+    ri, ra, rb = orc.match_l2_top2(q, t)
+    assert np.array_equal(idx0, ri)
+    j0, i0 = 123, 45
+    t2, q2 = t.copy(), q.copy()
+    t2[j0, 17] = np.nan; q2[i0, 3] = np.nan
+    idx, a, b = (x.cpu().numpy()[0] for x in matching.match_l2(torch.from_numpy(q2[None]).to(device),
+                                                               torch.from_numpy(t2[None]).to(device), precision=precision))
+    clean = np.arange(700) != i0
+    assert not (idx[clean] == j0).any()
+    # second-best of the clean run (exact, by the float64 matcher) must not be j0 either for the result to be comparable
+    d = ((q[:, None, :].astype(np.float64) - t[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    second = np.argsort(d, axis=1)[:, 1]
+    same = clean & (idx0 != j0) & (second != j0)
+    assert same.sum() > 600 and np.array_equal(idx[same], idx0[same]) and np.array_equal(a[same], a0[same])
