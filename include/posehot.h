@@ -258,6 +258,15 @@ int ph_triangulate(const float* P1, const float* P2,
  * R (9, row-major) | t (3) | inliers | matches | winning hypothesis | status (1 if inliers >= min_inliers). */
 int ph_gather_models(const float* models, const int32_t* sel, int B, int H, int stride,
                      float* out, void* stream);
+/* ph_compact_models: stable compaction of the non-empty models of every item's [H][stride] block (the solvers leave a slot
+ * all-zero when its root is not a solution: about half of the slots).  out [B][H][stride]: the live models first, in slot
+ * order, the tail zero-filled (must not alias `models`); slot [B][H]: the slot a compact position came from, -1 in the tail;
+ * n_live [B].  Scoring the compact block costs what its live models cost — a wave of eight empty slots leaves at once — and
+ * ph_select_best of its counts, mapped back with ph_lookup_index (out[b] = table[b][sel[b]], -1 outside [0, H)), is the
+ * winner of the slot layout, ties included (the order is kept).  No reference counterpart (glue of north_star's RANSAC). */
+int ph_compact_models(const float* models, int B, int H, int stride, float* out, int32_t* slot, int32_t* n_live,
+                      void* stream);
+int ph_lookup_index(const int32_t* table, const int32_t* sel, int B, int H, int32_t* out, void* stream);
 /* ph_decompose_essential: the recoverPose-style decomposition of hypothesis sel[b] (NULL = 0) of every item's
  * [H][9] block of essential matrices into its four (R, t) candidates, on the device (closed form, float64; no
  * reference counterpart — north_star leaves this step on the host, where pose_estimation_amd.geometry does it by

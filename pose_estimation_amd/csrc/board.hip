@@ -301,37 +301,71 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
             for (int k = 0; k < 28; ++k) red[wave][k] = acc[k];
         __syncthreads();
         if (tid == 0) {
+            // every loop of this serial part is unrolled on constant indices: the small matrices stay in registers
+            // (dynamic indexing put them in scratch memory — an L2 round trip per access)
             double s[28];
-            for (int k = 0; k < 28; ++k) { s[k] = 0.0; for (int w = 0; w < NW; ++w) s[k] += red[w][k]; }
+#pragma unroll
+            for (int k = 0; k < 28; ++k) {
+                s[k] = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s[k] += red[w][k];
+            }
             cost = s[27];
             sh_cost = cost;
             // damped system (Marquardt scaling), Cholesky
             double A[6][6], g[6], L[6][6], dlt[6];
-            int q = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int c = a; c < 6; ++c) { A[a][c] = s[q]; A[c][a] = s[q]; ++q; }
+            {
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int c = a; c < 6; ++c) { A[a][c] = s[q]; A[c][a] = s[q]; ++q; }
+            }
+#pragma unroll
             for (int a = 0; a < 6; ++a) { g[a] = -s[21 + a]; A[a][a] += lambda * A[a][a] + 1e-300; }
             bool ok = true;
-            for (int a = 0; a < 6 && ok; ++a)
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
                 for (int c = 0; c <= a; ++c) {
                     double v = A[a][c];
+#pragma unroll
                     for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
-                    if (a == c) { if (!(v > 0.0)) { ok = false; break; } L[a][a] = sqrt(v); }
+                    if (a == c) { ok = ok && (v > 0.0); L[a][a] = sqrt(fmax(v, 1e-300)); }
                     else L[a][c] = v / L[c][c];
                 }
             if (ok) {
-                for (int a = 0; a < 6; ++a) { double v = g[a]; for (int k = 0; k < a; ++k) v -= L[a][k] * dlt[k]; dlt[a] = v / L[a][a]; }
-                for (int a = 5; a >= 0; --a) { double v = dlt[a]; for (int k = a + 1; k < 6; ++k) v -= L[k][a] * dlt[k]; dlt[a] = v / L[a][a]; }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double v = g[a];
+#pragma unroll
+                    for (int k = 0; k < a; ++k) v -= L[a][k] * dlt[k];
+                    dlt[a] = v / L[a][a];
+                }
+#pragma unroll
+                for (int a = 5; a >= 0; --a) {
+                    double v = dlt[a];
+#pragma unroll
+                    for (int k = a + 1; k < 6; ++k) v -= L[k][a] * dlt[k];
+                    dlt[a] = v / L[a][a];
+                }
                 double dR[9], Rn[9], Rcur[9];
                 exp_so3(dlt, dR);
+#pragma unroll
                 for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
                 mat3_mul(dR, Rcur, Rn);
+#pragma unroll
                 for (int k = 0; k < 9; ++k) sh_Rc[k] = Rn[k];
+#pragma unroll
                 for (int k = 0; k < 3; ++k) sh_tc[k] = sh_t[k] + dlt[3 + k];
-                double n2 = 0; for (int a = 0; a < 6; ++a) n2 += dlt[a] * dlt[a];
+                double n2 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) n2 += dlt[a] * dlt[a];
                 sh_flag = (n2 < 1e-26) ? 1 : 0;
             } else {
+#pragma unroll
                 for (int k = 0; k < 9; ++k) sh_Rc[k] = sh_R[k];
+#pragma unroll
                 for (int k = 0; k < 3; ++k) sh_tc[k] = sh_t[k];
                 sh_flag = 2;                                   // not positive definite: just raise lambda
             }
@@ -536,7 +570,7 @@ extern "C" int ph_refine_pose_lm(const float* obj, const float* img, const int32
         hipLaunchKernelGGL((refine_pose_kernel<PointsAoS, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, pts, n_valid, N,
                            K4, dist5, max_iters, pose, rms, iters);
     else
-        hipLaunchKernelGGL((refine_pose_kernel<PointsAoS, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, pts, n_valid,
+        hipLaunchKernelGGL((refine_pose_kernel<PointsAoS, 512>), dim3(B), dim3(512), 0, (hipStream_t)stream, pts, n_valid,
                            N, K4, dist5, max_iters, pose, rms, iters);
     return ph_launch_status();
 }
@@ -553,7 +587,7 @@ extern "C" int ph_refine_pose_lm_soa(const float* X, const float* Y, const float
         hipLaunchKernelGGL((refine_pose_kernel<PointsSoA, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, pts, n_valid, N,
                            K4, dist5, max_iters, pose, rms, iters);
     else
-        hipLaunchKernelGGL((refine_pose_kernel<PointsSoA, 1024>), dim3(B), dim3(1024), 0, (hipStream_t)stream, pts, n_valid,
+        hipLaunchKernelGGL((refine_pose_kernel<PointsSoA, 512>), dim3(B), dim3(512), 0, (hipStream_t)stream, pts, n_valid,
                            N, K4, dist5, max_iters, pose, rms, iters);
     return ph_launch_status();
 }

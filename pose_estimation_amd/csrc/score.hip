@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
         }
     }
     int cnt[kHPW];
+    bool wave_live = false;                                // a wave of empty slots (the tail of a compacted block) leaves at once
 #pragma unroll
-    for (int k = 0; k < kHPW; ++k) cnt[k] = 0;
+    for (int k = 0; k < kHPW; ++k) { cnt[k] = 0; wave_live |= live[k]; }
 
     const size_t row = (size_t)b * N;
     int known = 0;                                         // best count of the item this wave knows of
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
     int rot = (blockIdx.x * 4 + wave) & (kRep - 1);
     int pending = 0;
     if (Bail) pending = __hip_atomic_load(lbp + rot * kRepStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int c0 = p_begin; c0 < p_end; c0 += 64 * kPPL) {
+    for (int c0 = p_begin; c0 < p_end && wave_live; c0 += 64 * kPPL) {
         if (Bail) {
             const int seen = __builtin_amdgcn_readfirstlane(pending);
             if (known > seen && lane == 0) atomicMax(lbp + rot * kRepStride, known);

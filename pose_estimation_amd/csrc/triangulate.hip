@@ -169,6 +169,62 @@ __global__ __launch_bounds__(256) void gather_models_kernel(const float* __restr
     out[i] = models[((size_t)b * H + h) * stride + e];
 }
 
+// Stable compaction of the non-empty models of every item (the solvers leave a slot all-zero when its root is not a
+// solution: 53 % of the 5-point slots, 55 % of the P3P slots): live models first, in slot order, the tail zero-filled,
+// plus the map compact position -> slot.  One 1024-thread block per item; per round of 1024 slots a ballot / popcount
+// prefix inside the waves and a 16-entry table across them.
+__global__ __launch_bounds__(1024) void compact_models_kernel(const float* __restrict__ models, int H, int stride,
+                                                             float* __restrict__ out, int32_t* __restrict__ slot,
+                                                             int32_t* __restrict__ n_live) {
+    __shared__ int wsum[16];
+    __shared__ int base_sh;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* M = models + (size_t)b * H * stride;
+    float* O = out + (size_t)b * H * stride;
+    int32_t* S = slot + (size_t)b * H;
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int h0 = 0; h0 < H; h0 += 1024) {
+        const int h = h0 + tid;
+        bool live = false;
+        if (h < H) {
+            uint32_t any = 0;
+            for (int e = 0; e < stride; ++e) any |= __float_as_uint(M[(size_t)h * stride + e]) << 1;      // +-0 -> 0
+            live = any != 0u;
+        }
+        const unsigned long long votes = __ballot(live);
+        const int before = __popcll(votes & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(votes);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; woff += (w < wave) ? c : 0; total += c; }
+        const int base = base_sh;
+        if (live) {
+            const int pos = base + woff + before;
+            for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = M[(size_t)h * stride + e];
+            S[pos] = h;
+        }
+        __syncthreads();
+        if (tid == 0) base_sh = base + total;
+        __syncthreads();
+    }
+    const int n = base_sh;
+    for (int pos = n + tid; pos < H; pos += 1024) {
+        for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = 0.0f;
+        S[pos] = -1;
+    }
+    if (tid == 0) n_live[b] = n;
+}
+
+// out[b] = table[b][sel[b]] (-1 when sel[b] is outside [0, H)): compact position of a winner -> its slot
+__global__ __launch_bounds__(64) void lookup_index_kernel(const int32_t* __restrict__ table, const int32_t* __restrict__ sel, int B,
+                                                         int H, int32_t* __restrict__ out) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const int s = sel[b];
+    out[b] = (s >= 0 && s < H) ? table[(size_t)b * H + s] : -1;
+}
+
 // Cheirality winner and pose-table row of every item: win = argmax_c front[b][c] (first maximum), table row =
 // R (9, row-major) | t (3) of P2[b][win] = [R | t], inliers, matches, winning hypothesis, status.
 __global__ __launch_bounds__(64) void pose_table_kernel(const float* __restrict__ P2, const int32_t* __restrict__ front, int C,
@@ -303,6 +359,24 @@ extern "C" int ph_gather_models(const float* models, const int32_t* sel, int B, 
     if (!models || !out) return PH_ERR_INVALID_ARG;
     hipLaunchKernelGGL(gather_models_kernel, dim3(ph_ceil_div(B * stride, 256)), dim3(256), 0, (hipStream_t)stream, models, sel,
                        B, H, stride, out);
+    return ph_launch_status();
+}
+
+extern "C" int ph_compact_models(const float* models, int B, int H, int stride, float* out, int32_t* slot, int32_t* n_live,
+                                 void* stream) {
+    if (B < 0 || H < 0 || stride < 1) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0) return PH_OK;
+    if (!n_live || (H > 0 && (!models || !out || !slot)) || models == out) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(compact_models_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
+    return ph_launch_status();
+}
+
+extern "C" int ph_lookup_index(const int32_t* table, const int32_t* sel, int B, int H, int32_t* out, void* stream) {
+    if (B < 0 || H < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!sel || !out || (H > 0 && !table)) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(lookup_index_kernel, dim3(ph_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, table, sel, B, H, out);
     return ph_launch_status();
 }
 

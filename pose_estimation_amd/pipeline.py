@@ -69,14 +69,23 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     pts = (m["x1"], m["y1"], m["x2"], m["y2"])
     extra = {}
     front_opts = dict(thr_sq=float(thr_sq), refine=bool(refine))
+    generated = E_hyp is None
     if E_hyp is None:
         samples = ransac.sample_minimal(seed, m["n_match"], pts[0].shape[1], n_samples, item_key=item_key)
         if want_counts:
             E_hyp, extra["n_solutions"] = ransac.solve_essential_5pt(*pts, samples, want_counts=True)
         else:
             E_hyp = ransac.solve_essential_5pt(*pts, samples)
-    cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"], bailout=True)    # only the winner is read
-    bi, bc = ransac.select_best(cnt)
+    if generated:
+        # about half of the solver's slots are empty: score the live models packed together (a wave of eight empty
+        # slots leaves at once), then map the winner's compact position back to its slot — same winner, ties included
+        Ec, slot_map, _ = ransac.compact_models(E_hyp)
+        cnt = ransac.score_essential(Ec, *pts, thr_sq, m["n_match"], bailout=True)   # only the winner is read
+        bi_c, bc = ransac.select_best(cnt)
+        bi = ransac.lookup_index(slot_map, bi_c)
+    else:
+        cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"], bailout=True)    # only the winner is read
+        bi, bc = ransac.select_best(cnt)
     mask = ransac.inlier_mask_essential(E_hyp, bi, *pts, thr_sq, m["n_match"])
     if decompose == "device":
         return Front(pts, m["n_match"], E_hyp, bi, bc, mask, None, None, want_points, extra, front_opts)
@@ -128,7 +137,8 @@ def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
                                                   refine))
 
 
-def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096, seed=0, refine=True, max_iters=20):
+def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096, seed=0, refine=True, max_iters=20,
+                        want_counts=False):
     """RANSAC absolute pose (PnP) of B frames from 2-D/3-D correspondences, all on the device (SURVEY.md §8d cfg 5):
 
         Philox 3-point samples -> P3P (4 hypothesis slots per sample) -> score H = 4*n_samples hypotheses
@@ -137,19 +147,27 @@ def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096,
 
     X, Y, Z, u, v: float32 ``[B, N]`` SoA rows, (u, v) undistorted pixels; K4 = (fx, fy, cx, cy) float64 device
     tensor.  Returns dict(pose [B,6] f64 (rvec, tvec), pose0 (the winning minimal hypothesis), best_count,
-    best_idx, count [B,H] (exact for the winner, lower bounds for abandoned hypotheses), mask, rms, iters, P_hyp)."""
+    best_idx (slot), count [B,H] (of P_compact's order: exact for the winner, lower bounds for abandoned hypotheses), mask, rms,
+    iters, P_hyp (slot layout), P_compact / slot_map (the live models packed, and the slot each came from))."""
     fx, fy, cx, cy = (K4[k].to(torch.float32) for k in range(4))
     xn, yn = (u - cx) / fx, (v - cy) / fy
     B, N = X.shape
     thr_sq = float(thr_px) ** 2
     samples = ransac.sample_minimal(seed, n_valid, N, n_samples, m=3) if n_valid is not None else \
         ransac.sample_minimal(seed, torch.full((B,), N, dtype=torch.int32, device=X.device), N, n_samples, m=3)
-    P = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4)
-    cnt = ransac.score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid, bailout=True)           # only the winner is read
-    bi, bc = ransac.select_best(cnt)
+    if want_counts:             # n_solutions [B, n_samples]: real models per minimal sample (a slot holds a model only for a solution)
+        P, n_sol = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4, want_counts=True)
+    else:
+        P, n_sol = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4), None
+    Pc, slot_map, _ = ransac.compact_models(P)                                         # live models packed (see relative_pose_front)
+    cnt = ransac.score_pnp(Pc, X, Y, Z, u, v, thr_sq, n_valid, bailout=True)          # only the winner is read; compact order
+    bi_c, bc = ransac.select_best(cnt)
+    bi = ransac.lookup_index(slot_map, bi_c)
     mask = ransac.inlier_mask_pnp(P, bi, X, Y, Z, u, v, thr_sq, n_valid)
     pose0 = ransac.pose_from_projection(P, bi, K4)
-    out = dict(pose0=pose0, best_count=bc, best_idx=bi, mask=mask, P_hyp=P, count=cnt)
+    out = dict(pose0=pose0, best_count=bc, best_idx=bi, mask=mask, P_hyp=P, count=cnt, P_compact=Pc, slot_map=slot_map)
+    if n_sol is not None:
+        out["n_solutions"] = n_sol
     if refine:
         pose, rms, iters = ransac.refine_pose_lm_soa(X, Y, Z, u, v, pose0, K4, None, mask, n_valid, max_iters)
         out.update(pose=pose, rms=rms, iters=iters)

@@ -95,6 +95,33 @@ def gather_models(models, sel):
     return out
 
 
+def compact_models(models):
+    """Live (non-zero) models of every item first, in slot order: returns (compact ``[B, H, stride]`` with a zero tail,
+    slot map int32 ``[B, H]`` (-1 in the tail), n_live int32 ``[B]``)."""
+    lib = L.load()
+    models = L.dev(models, torch.float32, "models")
+    if models.dim() != 3:
+        raise ValueError("models must be [B, H, stride]")
+    B, H, stride = models.shape
+    out = torch.empty_like(models)
+    slot = torch.empty((B, H), dtype=torch.int32, device=models.device)
+    n_live = torch.empty((B,), dtype=torch.int32, device=models.device)
+    L.check(lib.ph_compact_models(L.ptr(models), B, H, stride, L.ptr(out), L.ptr(slot), L.ptr(n_live), L.stream_ptr()),
+            "ph_compact_models")
+    return out, slot, n_live
+
+
+def lookup_index(table, sel):
+    """``table[b, sel[b]]`` int32 ``[B]`` (-1 where sel[b] is out of range): a compact winner's slot."""
+    lib = L.load()
+    table = L.dev(table, torch.int32, "table")
+    B, H = table.shape
+    sel = L.opt_i32(sel, B, "sel")
+    out = torch.empty((B,), dtype=torch.int32, device=table.device)
+    L.check(lib.ph_lookup_index(L.ptr(table), L.ptr(sel), B, H, L.ptr(out), L.stream_ptr()), "ph_lookup_index")
+    return out
+
+
 def decompose_essential(E, sel=None):
     """The four (R, t) candidates of hypothesis sel[b] of each item's ``[H, 9]`` block, on the device.
 

@@ -31,6 +31,7 @@ def test_absolute_pose_pipeline(device):
     K4 = _t(orc.K4, device)
     out = pipeline.absolute_pose_batch(*pts, K4, thr_px=8.0, n_valid=_t(n_valid, device), n_samples=S, seed=3, max_iters=30)
     P = out["P_hyp"].cpu().numpy()
+    Pc, smap = out["P_compact"].cpu().numpy(), out["slot_map"].cpu().numpy()      # live models packed, and where each came from
     cnt, bi, bc = out["count"].cpu().numpy(), out["best_idx"].cpu().numpy(), out["best_count"].cpu().numpy()
     mask = out["mask"].cpu().numpy().view(np.uint64)
     pose0, pose, rms = out["pose0"].cpu().numpy(), out["pose"].cpu().numpy(), out["rms"].cpu().numpy()
@@ -38,10 +39,14 @@ def test_absolute_pose_pipeline(device):
     for b in range(B):
         nv = int(n_valid[b])
         a = [fr[k][b, :nv] for k in "XYZuv"]
-        rc = orc.score_pnp(P[b], *a, 64.0)
+        live = np.abs(P[b]).sum(axis=1) > 0
+        assert np.array_equal(Pc[b, :live.sum()], P[b][live]) and not Pc[b, live.sum():].any()
+        assert np.array_equal(smap[b, :live.sum()], np.nonzero(live)[0]) and (smap[b, live.sum():] == -1).all()
+        rc = orc.score_pnp(Pc[b], *a, 64.0)
         assert np.array_equal(rc, cnt[b])
         rbi, rbc = orc.select_best(rc)
-        assert (rbi, rbc) == (bi[b], bc[b])
+        assert (smap[b, rbi], rbc) == (bi[b], bc[b])
+        assert (bi[b], bc[b]) == orc.select_best(orc.score_pnp(P[b], *a, 64.0))       # = the winner of the slot layout
         rmask = orc.inlier_mask_pnp(P[b, bi[b]], *a, 64.0, N)
         assert np.array_equal(rmask, mask[b])
         inl = orc.unpack_mask(mask[b], N)[:nv]

@@ -109,3 +109,28 @@ def test_score_pnp_behind_camera_is_outlier(device):
     z = _t(X, device)
     cnt = ransac.score_pnp(_t(P, device), z, z, _t(Z, device), z, z, 1.0).cpu().numpy()
     assert cnt[0, 0] == 1
+
+
+def test_compact_models_and_lookup(device):
+    """ph_compact_models: live models first in slot order, zero tail, slot map; scoring the compact block and mapping the
+    winner back gives the winner of the slot layout (ties -> lowest slot), for E (stride 9) and P (stride 12)."""
+    from pose_estimation_amd import ransac
+    rng = np.random.default_rng(12)
+    for stride, H in ((9, 2500), (12, 1030), (9, 7)):
+        B = 3
+        M = rng.normal(size=(B, H, stride)).astype(np.float32)
+        dead = rng.random((B, H)) < 0.55
+        dead[1] = True; dead[2, :] = False                   # an item without any live model, one without an empty slot
+        M[dead] = 0.0
+        M[0, 5] = M[0, 3]                                    # a tie between two live slots
+        M[0, 1, 0] = -0.0 if dead[0, 1] else M[0, 1, 0]      # a negative zero is still an empty slot
+        Mc, smap, nl = ransac.compact_models(torch.from_numpy(M).to(device))
+        Mc, smap, nl = Mc.cpu().numpy(), smap.cpu().numpy(), nl.cpu().numpy()
+        for b in range(B):
+            live = np.abs(M[b]).sum(axis=1) > 0
+            n = int(live.sum())
+            assert nl[b] == n and np.array_equal(Mc[b, :n], M[b][live]) and not Mc[b, n:].any()
+            assert np.array_equal(smap[b, :n], np.nonzero(live)[0]) and (smap[b, n:] == -1).all()
+        sel = torch.tensor([0, 5, H], dtype=torch.int32, device=device)
+        got = ransac.lookup_index(torch.from_numpy(smap).to(device), sel).cpu().numpy()
+        assert got[0] == smap[0, 0] and got[1] == -1 and got[2] == -1
