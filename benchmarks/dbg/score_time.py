@@ -15,6 +15,8 @@ pts = (m["x1"], m["y1"], m["x2"], m["y2"])
 samples = ransac.sample_minimal(1000, m["n_match"], 8192, S)
 E, ns = ransac.solve_essential_5pt(*pts, samples, want_counts=True)
 thr_sq = float(np.float32((1.0 / synthetic.FX) ** 2))
+E_slots = E
+E, smap, nlive = ransac.compact_models(E)     # what the pipeline scores
 print("matches", m["n_match"].float().mean().item(), "real models", ns.sum(1).float().mean().item())
 def timeit(f, n=6):
     ts = []

@@ -56,6 +56,24 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     float Pa[12], Pb[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) { Pa[e] = pa[e]; Pb[e] = pb[e]; }
+    // Twin candidates.  The four (R, t) candidates of an essential matrix come as (Ra, t), (Ra, -t), (Rb, t), (Rb, -t) with
+    // P1 = [I | 0]: negating the fourth column of both projection matrices mirrors the DLT system (A' = A diag(1,1,1,-1)),
+    // every Jacobi rotation, the null vector's last component and with it X and both depths — exactly, sign flips being
+    // exact in IEEE arithmetic.  So an even candidate whose successor is such a twin computes once and reports for both
+    // (X' = -X, the twin's vote = both depths NEGATIVE), and the twin's own blocks leave at once.
+    auto twin_of = [&](int ce, int co) {                   // is candidate co the fourth-column mirror of candidate ce?
+        const float* qa = P1 + ((size_t)b * C + ce) * 12; const float* ra = P1 + ((size_t)b * C + co) * 12;
+        const float* qb = P2 + ((size_t)b * C + ce) * 12; const float* rb = P2 + ((size_t)b * C + co) * 12;
+        bool same = true;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const bool col4 = (e & 3) == 3;
+            same = same && (col4 ? (ra[e] == -qa[e] && rb[e] == -qb[e]) : (ra[e] == qa[e] && rb[e] == qb[e]));
+        }
+        return same;
+    };
+    if ((c & 1) && twin_of(c - 1, c)) return;              // wave-uniform (the matrices are per item and candidate)
+    const bool has_twin = !(c & 1) && (c + 1 < C) && twin_of(c, c + 1);
 
     const size_t o = (size_t)b * N + (ok ? i : 0);
     const float u1 = x1[o], v1 = y1[o], u2 = x2[o], v2 = y2[o];
@@ -90,6 +108,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     if (ok && XYZ) {
         float* dst = XYZ + (((size_t)b * C + c) * N + i) * 3;
         dst[0] = X; dst[1] = Y; dst[2] = Z;
+        if (has_twin) { dst += (size_t)N * 3; dst[0] = -X; dst[1] = -Y; dst[2] = -Z; }
     }
     if (front) {
         const float z1 = ph_fma(Pa[8], X, ph_fma(Pa[9], Y, ph_fma(Pa[10], Z, Pa[11])));
@@ -98,6 +117,10 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
         if (mask && ok) sel = (mask[(size_t)b * ((N + 63) / 64) + (i >> 6)] >> (i & 63)) & 1ull;
         const unsigned long long votes = __ballot(sel && z1 > 0.0f && z2 > 0.0f);
         if ((threadIdx.x & 63) == 0 && votes) atomicAdd(front + (size_t)b * C + c, (int32_t)__popcll(votes));
+        if (has_twin) {
+            const unsigned long long tv = __ballot(sel && z1 < 0.0f && z2 < 0.0f);
+            if ((threadIdx.x & 63) == 0 && tv) atomicAdd(front + (size_t)b * C + c + 1, (int32_t)__popcll(tv));
+        }
     }
 }
 

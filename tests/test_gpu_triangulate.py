@@ -104,3 +104,31 @@ def test_gather_models_and_pose_table(device):
     assert np.array_equal(t[:, 12], bc.cpu().numpy().astype(np.float32)) and np.array_equal(t[:, 13], nm.cpu().numpy().astype(np.float32))
     assert np.array_equal(t[:, 14], bidx.cpu().numpy().astype(np.float32))
     assert np.array_equal(t[:, 15], (bc.cpu().numpy() >= 5).astype(np.float32))
+
+
+def test_twin_candidates_share_one_triangulation_bit_exactly(device):
+    """(R, t) and (R, -t) mirror each other's DLT system: the kernel computes such a pair once.  Points and votes of the
+    four-candidate call must equal — bit for bit — those of four separate single-candidate calls (no twins to detect),
+    and a non-twin layout (candidates permuted) must give the same numbers per candidate."""
+    n = 3000
+    X, x1, x2, P1, P2, R, t = _scene(14, n, 1 / 3108.95)
+    Rb = synthetic.rot_x(0.3) @ R
+    cands = [(R, t), (R, -t), (Rb, t), (Rb, -t)]
+    P2c = np.stack([synthetic.projection_matrix(Rc, tc, pixels=False) for Rc, tc in cands]).astype(np.float32)
+    P1c = np.repeat(P1[None], 4, 0)
+    rng = np.random.default_rng(2)
+    sel = rng.random(n) < 0.7
+    words = np.packbits(np.pad(sel, (0, (-n) % 64)), bitorder="little").view(np.uint64).view(np.int64)[None]
+    pts = [_t(a[None], device) for a in (x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1])]
+    xyz4, f4 = triangulation.triangulate(_t(P1c[None], device), _t(P2c[None], device), *pts, mask=_t(words, device), want_front=True)
+    xyz4, f4 = xyz4.cpu().numpy()[0], f4.cpu().numpy()[0]
+    for c in range(4):
+        xyz1, f1 = triangulation.triangulate(_t(P1c[None, c:c + 1], device), _t(P2c[None, c:c + 1], device), *pts,
+                                             mask=_t(words, device), want_front=True)
+        assert np.array_equal(xyz1.cpu().numpy()[0, 0].view(np.uint32), xyz4[c].view(np.uint32)), c
+        assert int(f1[0, 0]) == f4[c], c
+    assert f4[0] > 0.65 * n and f4[1] == 0                      # the true pose has the selected points in front, its mirror none
+    perm = [0, 2, 1, 3]                                         # no candidate is followed by its twin
+    xyzp, fp = triangulation.triangulate(_t(P1c[None][:, perm], device), _t(P2c[None][:, perm], device), *pts,
+                                         mask=_t(words, device), want_front=True)
+    assert np.array_equal(fp.cpu().numpy()[0], f4[perm]) and np.array_equal(xyzp.cpu().numpy()[0].view(np.uint32), xyz4[perm].view(np.uint32))
