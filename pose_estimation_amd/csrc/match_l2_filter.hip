@@ -28,8 +28,13 @@
 // over ALL rows inside the same kernel: slower, never wrong.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "match_l2_filter.hpp"
+#ifndef PH_ABLATE
+#define PH_ABLATE 0
+#endif
 
 namespace {
 
@@ -89,6 +94,15 @@ __device__ __forceinline__ uint4 to_f16x8(const float4 a, const float4 b, float 
 // read hazard only for instructions it can see into (an asm v_max reading the accumulator right behind the last MFMA
 // reads stale registers).  This file is built with -fno-honor-nans, so fmaxf is a single v_max_f32.
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
+
+// The value of x in the lane of the same number of the lower (lo) and of the upper (hi) half of the wave, in every lane:
+// one v_permlane32_swap (VALU) instead of a ds_bpermute round trip through the LDS pipe, the busiest unit of the filter.
+// Callers use lo and hi symmetrically (max, min, median), so which one is "mine" does not matter.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r.x); hi = __uint_as_float(r.y);
+}
 
 __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
@@ -164,6 +178,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a scalar base address and a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16s(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
@@ -236,14 +256,30 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     const int n_tiles = (t_end - t_begin + kSR - 1) / kSR;
     const int n_prime = min(kPrimeRows / kSR, max(1, n_tiles / 8));
 
-    // staged tile -> LDS buffer: wave w copies KB slices w, w+4, ... and its share of the tail, asynchronously
+    // staged tile -> LDS buffer: wave w copies KB slices w, w+4, ... and its share of the tail, asynchronously.  Scalar base
+    // + one per-lane offset register that never changes (tid * 16): a copy costs scalar adds and the DMA instruction itself,
+    // no vector instruction (vector address arithmetic in front of every copy sat between the barrier and the first MFMA
+    // of every wave: 0.15 of the kernel's time, measured by leaving the copies out).
+    const unsigned wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned voff = (unsigned)tid * 16u;
     auto stage = [&](int tile, int buf) {
-        const uint4* src = IMG + (size_t)tile * kImg;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + wave * 64));
+#if PH_ABLATE & 32
+        const char* src = (const char*)(IMG + (size_t)(tile & 1) * kImg);
+#else
+        const char* src = (const char*)(IMG + (size_t)tile * kImg);
+#endif
+        const unsigned dst = lds_addr(smem) + (unsigned)buf * (kImg * 16u) + wave_s * 1024u;
 #pragma unroll
-        for (int u = 0; u < kImgRows / 256; ++u) glds16(src + (wave + 4 * u) * 64 + lane, dst + 4096u * u);
-        const unsigned dst_tail = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kImg + kImgRows + wave * (kImgTail / 4)));
-        if (lane < kImgTail / 4) glds16(src + kImgRows + wave * (kImgTail / 4) + lane, dst_tail);
+        for (int u = 0; u < kImgRows / 256; ++u) {
+#if PH_ABLATE & 16
+            if (u >= 2) break;
+#endif
+            glds16s(src + 4096 * u, voff, dst + 4096u * u);
+        }
+        // tail: lane l of wave w copies chunk w * (kImgTail / 4) + l; the lane offset register carries w * 1024 too much
+        if (lane < kImgTail / 4)
+            glds16s(src + kImgRows * 16 + (long)wave_s * (kImgTail / 4 * 16) - (long)wave_s * 1024, voff,
+                    lds_addr(smem) + (unsigned)buf * (kImg * 16u) + kImgRows * 16u + wave_s * (kImgTail / 4 * 16u));
     };
 
     // The two MFMA tiles of a staged tile are worked on one after the other (fragments and presets of a tile are read up
@@ -251,24 +287,42 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     // — then its MFMA chains run back to back, then its scores are filtered): one tile's fragments and accumulators live
     // at a time keep the kernel at <= 168 VGPR, which leaves the third wave slot of every SIMD to the other kernels of
     // the step (re-rank, solver, scoring: 120-128 VGPR) when batches overlap on several streams.
-    auto tile_scores = [&](int buf, int sub, f32x16 (&acc)[kQT]) {
-        uint4 af[kNS];
-        const uint4* rh = smem + buf * kImg + sub * (kTR * kCPR) + li * kCPR;
+    // Per-lane byte offsets of the eight A fragments inside an MFMA tile and of the lane half's presets: computed once;
+    // the ring slot and the sub-tile are compile-time constants (the tile loop is unrolled over the ring), so every LDS
+    // read is "register + immediate" and no vector instruction stands between the barrier and the first MFMA.
+    unsigned aoff[kNS];
 #pragma unroll
-        for (int s = 0; s < kNS; ++s) af[s] = rh[(2 * s + h) ^ (li & 15)];
-        const float4* tnl = (const float4*)(smem + buf * kImg + kImgRows) + sub * (kTR / 4);
+    for (int s = 0; s < kNS; ++s) aoff[s] = (unsigned)(li * kCPR + ((2 * s + h) ^ (li & 15))) * 16u;
+    const unsigned poff = (unsigned)h * 16u;
+    auto tile_scores = [&](auto bufc, auto subc, f32x16 (&acc)[kQT]) {
+        constexpr unsigned base = decltype(bufc)::value * (kImg * 16u) + decltype(subc)::value * (kTR * kCPR * 16u);
+        constexpr unsigned pbase = decltype(bufc)::value * (kImg * 16u) + kImgRows * 16u + decltype(subc)::value * (kTR * 4u);
+        const char* sm = (const char*)smem;
+        auto frag = [&](int s) {
+#if PH_ABLATE & 2
+            return bh[0][s ^ 1];
+#else
+            return *(const uint4*)(sm + (aoff[s] + base));
+#endif
+        };
+        // issue order pinned by hand (scheduling barriers): presets and two fragments up front, then one fragment read
+        // per k-step, two steps ahead of the MFMAs that consume it
+        uint4 af[kNS];
+        af[0] = frag(0);
         f32x16 preset;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 z = tnl[2 * g + h];                           // rows 8g + 4h .. +3
+            const float4 z = *(const float4*)(sm + (poff + (pbase + 32u * g)));     // rows 8g + 4h .. +3
             preset[4 * g + 0] = z.x; preset[4 * g + 1] = z.y; preset[4 * g + 2] = z.z; preset[4 * g + 3] = z.w;
         }
+        af[1] = frag(1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[0], bh[ct][0], preset);
+        for (int s = 0; s < kNS; ++s) {
+            if (s + 2 < kNS) af[s + 2] = frag(s + 2);
 #pragma unroll
-        for (int s = 1; s < kNS; ++s) {
-#pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[s], bh[ct][s], acc[ct]);
+            for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[s], bh[ct][s], s == 0 ? preset : acc[ct]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -330,9 +384,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         }
         // the other lane half holds the same query (its other rows): the second-largest of the union of the two
         // halves' top-2 is the tighter bound — half of the time the best two rows sit in different halves
-        const float o1 = __shfl_xor(a1[ct], 32), o2 = __shfl_xor(a2[ct], 32), ot = __shfl_xor(thr[ct], 32);
-        const float second = vmax(fminf(a1[ct], o1), vmax(a2[ct], o2));
-        thr[ct] = vmax(vmax(thr[ct], ot), second - eps2[ct]);
+        float l1, h1, l2, h2, lt, ht;
+        both_halves(a1[ct], l1, h1); both_halves(a2[ct], l2, h2); both_halves(thr[ct], lt, ht);
+        const float second = vmax(fminf(l1, h1), vmax(l2, h2));
+        thr[ct] = vmax(vmax(lt, ht), second - eps2[ct]);
     };
 
     // Staging pipeline: a ring of kDepth + 1 LDS buffers, one barrier per staged tile, copies kDepth tiles ahead.  At
@@ -348,7 +403,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         static_assert(kDepth <= 4, "one case per possible count below");
         if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kGlds) : "memory");
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kGlds) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PH_ABLATE & 16) ? kGlds - 2 : kGlds) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     const int n_iter = n_prime + n_tiles;
@@ -357,19 +412,30 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     for (int d = 0; d < kDepth; ++d)
         if (d < n_iter) stage(tile_of(d), d);
     wait_ahead(min(kDepth, n_iter) - 1);
-    int cur = 0, nxt = kDepth;
-    for (int it = 0; it < n_iter; ++it) {
+    static_assert(kDepth + 1 == 3 && kSub == 2, "the tile loop below is unrolled over a ring of three buffers");
+    auto iteration = [&](auto bufc, int it) {
+        constexpr int BUF = decltype(bufc)::value, NXT = (BUF + kDepth) % (kDepth + 1);
         const bool priming = it < n_prime;
         const int t0 = tile_of(it) * kSR;
+#if !(PH_ABLATE & 8)
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
-        if (it + kDepth < n_iter) stage(tile_of(it + kDepth), nxt);
-#pragma unroll
-        for (int sub = 0; sub < kSub; ++sub) {
+#if !(PH_ABLATE & 4)
+        if (it + kDepth < n_iter) stage(tile_of(it + kDepth), NXT);
+#endif
+        auto work = [&](auto subc) {
+            constexpr int sub = decltype(subc)::value;
             f32x16 acc[kQT];
-            tile_scores(cur, sub, acc);
+            tile_scores(bufc, subc, acc);
             // tile it+1 landed (waited for before the first list store of this iteration is issued: the counter retires in order)
             if (sub == 0) wait_ahead(min(kDepth, n_iter - 1 - it) - 1 < 0 ? 0 : min(kDepth, n_iter - 1 - it) - 1);
+#if PH_ABLATE & 1
+            if (true) {
+#pragma unroll
+                for (int ct = 0; ct < kQT; ++ct) asm volatile("" :: "v"(acc[ct]));
+            } else
+#endif
             if (priming) {
 #pragma unroll
                 for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
@@ -377,20 +443,26 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
 #pragma unroll
                 for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0 + sub * kTR);
             }
-        }
+        };
+        work(std::integral_constant<int, 0>{});
+        work(std::integral_constant<int, 1>{});
         if (it + 1 == n_prime) {
 #pragma unroll
             for (int ct = 0; ct < kQT; ++ct) {
                 // second-largest of the union of the two halves' top-2, then restart the tracking: the primed
                 // rows are seen again by the filtering pass
-                const float o1 = __shfl_xor(a1[ct], 32), o2 = __shfl_xor(a2[ct], 32);
-                const float second = fmaxf(fminf(a1[ct], o1), fmaxf(a2[ct], o2));
+                float l1, h1, l2, h2;
+                both_halves(a1[ct], l1, h1); both_halves(a2[ct], l2, h2);
+                const float second = fmaxf(fminf(l1, h1), fmaxf(l2, h2));
                 thr[ct] = fmaxf(thr[ct], second - eps2[ct]);
                 a1[ct] = -INFINITY; a2[ct] = -INFINITY;
             }
         }
-        cur = cur == kDepth ? 0 : cur + 1;
-        nxt = nxt == kDepth ? 0 : nxt + 1;
+    };
+    for (int it = 0; it < n_iter; it += kDepth + 1) {
+        iteration(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < n_iter) iteration(std::integral_constant<int, 1>{}, it + 1);
+        if (it + 2 < n_iter) iteration(std::integral_constant<int, 2>{}, it + 2);
     }
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct)
