@@ -287,6 +287,22 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     // — then its MFMA chains run back to back, then its scores are filtered): one tile's fragments and accumulators live
     // at a time keep the kernel at <= 168 VGPR, which leaves the third wave slot of every SIMD to the other kernels of
     // the step (re-rank, solver, scoring: 120-128 VGPR) when batches overlap on several streams.
+    // The other lane half holds the same query (its other rows): the second-largest of the union of the two halves'
+    // top-2 is the tighter bound — half of the time the best two rows sit in different halves.  Once per staged tile,
+    // unconditionally (some lane of the wave has a hit in nearly every staged tile; thr is the same in both halves; a bound
+    // formed during priming is as valid as any), in two pieces of 4-5 vector instructions that are placed BETWEEN the
+    // MFMAs of the first sub-tile: a wave's own MFMAs hide about four vector instructions per MFMA pair
+    // (profiles/r2/mfma_valu_overlap.txt) and nothing else of the filter is independent of the accumulators.
+    float sw[4];
+    auto tighten_swap = [&](int ct) {
+        both_halves(a1[ct], sw[0], sw[1]); both_halves(a2[ct], sw[2], sw[3]);
+        asm volatile("" : "+v"(sw[0]), "+v"(sw[1]), "+v"(sw[2]), "+v"(sw[3]));
+    };
+    auto tighten_fold = [&](int ct) {
+        const float second = vmax(fminf(sw[0], sw[1]), vmax(sw[2], sw[3]));
+        thr[ct] = vmax(thr[ct], second - eps2[ct]);
+        asm volatile("" : "+v"(thr[ct]));            // computed here, between the MFMAs, not sunk to its first use
+    };
     // Per-lane byte offsets of the eight A fragments inside an MFMA tile and of the lane half's presets: computed once;
     // the ring slot and the sub-tile are compile-time constants (the tile loop is unrolled over the ring), so every LDS
     // read is "register + immediate" and no vector instruction stands between the barrier and the first MFMA.
@@ -322,6 +338,13 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
             if (s + 2 < kNS) af[s + 2] = frag(s + 2);
 #pragma unroll
             for (int ct = 0; ct < kQT; ++ct) acc[ct] = mfma_f16(af[s], bh[ct][s], s == 0 ? preset : acc[ct]);
+            if (decltype(subc)::value == 0) {
+                static_assert(kQT == 2 && kNS >= 6, "placement of the bound update");
+                if (s == 1) tighten_swap(0);
+                if (s == 2) tighten_fold(0);
+                if (s == 4) tighten_swap(1);
+                if (s == 5) tighten_fold(1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -382,14 +405,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
                 for (int r = 0; r < 4; ++r) hit(r == k ? -INFINITY : acc[4 * g4 + r], t0s + 8 * g4 + r, ct);
             }
         }
-        // the other lane half holds the same query (its other rows): the second-largest of the union of the two
-        // halves' top-2 is the tighter bound — half of the time the best two rows sit in different halves
-        float l1, h1, l2, h2, lt, ht;
-        both_halves(a1[ct], l1, h1); both_halves(a2[ct], l2, h2); both_halves(thr[ct], lt, ht);
-        const float second = vmax(fminf(l1, h1), vmax(l2, h2));
-        thr[ct] = vmax(vmax(lt, ht), second - eps2[ct]);
     };
-
     // Staging pipeline: a ring of kDepth + 1 LDS buffers, one barrier per staged tile, copies kDepth tiles ahead.  At
     // the top of iteration `it` every wave has waited for its own share of tile `it` and the barrier makes the whole
     // image visible (and tells that everybody is done reading tile it-1, whose buffer the newest copy now overwrites).
