@@ -1,7 +1,7 @@
 """Exhaustive vs bail-out scoring time at the bench's shape (hypotheses generated from the pairs' own matches)."""
-import sys
+import os, sys
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from pose_estimation_amd import matching, ransac, synthetic
 dev = torch.device("cuda:0")
 P, S = int(sys.argv[1]) if len(sys.argv) > 1 else 32, 920
@@ -35,3 +35,5 @@ cnt = ce.float(); best = cnt.max(1, keepdim=True).values; N = m["n_match"].float
 p = cnt / N
 frac = torch.clamp((N - best) / (N - cnt).clamp(min=1), max=1.0)     # points seen before cnt + remaining < best (uniform inlier density)
 print("ideal bail-out work fraction", float((frac * live).sum() / live.sum()))
+tc, _ = timeit(lambda: ransac.compact_models(E_slots))
+print(f"compact_models (incl. output allocation) {tc:.1f} us")

@@ -194,49 +194,69 @@ __global__ __launch_bounds__(256) void gather_models_kernel(const float* __restr
 
 // Stable compaction of the non-empty models of every item (the solvers leave a slot all-zero when its root is not a
 // solution: 53 % of the 5-point slots, 55 % of the P3P slots): live models first, in slot order, the tail zero-filled,
-// plus the map compact position -> slot.  One 1024-thread block per item; per round of 1024 slots a ballot / popcount
-// prefix inside the waves and a 16-entry table across them.
-__global__ __launch_bounds__(1024) void compact_models_kernel(const float* __restrict__ models, int H, int stride,
+// plus the map compact position -> slot.  One 1024-thread block per item.
+// One 1024-thread block per item.  Per round of 65536 slots (one round for every shape of the pipelines): (1) slot h on
+// thread h mod 1024, the waves' ballots go to a table of 64-bit words; (2) wave 0 turns the table into exclusive prefix
+// counts; (3) every live slot is copied to base + prefix of its word + rank inside the word.  STRIDE = floats per model
+// when known at compile time (9, 12: the loads of a model are issued together instead of one round trip per float), 0 =
+// the run-time value.  29 us for 64 items x 9200 slots x 9 floats (39 us with a barrier-separated prefix per 1024 slots
+// and run-time stride); staging the models through LDS for fully coalesced accesses was slower (35 us), and so was
+// giving a thread 9 consecutive slots (98 us): what is left is the latency of 64 blocks walking 18 dependent rounds.
+template <int STRIDE>
+__global__ __launch_bounds__(1024) void compact_models_kernel(const float* __restrict__ models, int H, int stride_rt,
                                                              float* __restrict__ out, int32_t* __restrict__ slot,
                                                              int32_t* __restrict__ n_live) {
-    __shared__ int wsum[16];
-    __shared__ int base_sh;
+    const int stride = STRIDE > 0 ? STRIDE : stride_rt;
+    __shared__ unsigned long long mask[1024];
+    __shared__ int pref[1024];
+    __shared__ int total_sh;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* M = models + (size_t)b * H * stride;
     float* O = out + (size_t)b * H * stride;
     int32_t* S = slot + (size_t)b * H;
-    if (tid == 0) base_sh = 0;
-    __syncthreads();
-    for (int h0 = 0; h0 < H; h0 += 1024) {
-        const int h = h0 + tid;
-        bool live = false;
-        if (h < H) {
+    int base = 0;                                          // live models before this round (the same in every thread)
+    for (int h0 = 0; h0 < H; h0 += 65536) {
+        const int span = min(H - h0, 65536), nw = (span + 63) / 64;
+        for (int r = tid; r < nw * 64; r += 1024) {
             uint32_t any = 0;
-            for (int e = 0; e < stride; ++e) any |= __float_as_uint(M[(size_t)h * stride + e]) << 1;      // +-0 -> 0
-            live = any != 0u;
-        }
-        const unsigned long long votes = __ballot(live);
-        const int before = __popcll(votes & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(votes);
-        __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; woff += (w < wave) ? c : 0; total += c; }
-        const int base = base_sh;
-        if (live) {
-            const int pos = base + woff + before;
-            for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = M[(size_t)h * stride + e];
-            S[pos] = h;
+            if (r < span) {
+#pragma unroll
+                for (int e = 0; e < stride; ++e) any |= __float_as_uint(M[(size_t)(h0 + r) * stride + e]) << 1;      // +-0 -> 0
+            }
+            const unsigned long long votes = __ballot(any != 0u);
+            if (lane == 0) mask[r >> 6] = votes;
         }
         __syncthreads();
-        if (tid == 0) base_sh = base + total;
+        if (wave == 0) {
+            const int per = (nw + 63) / 64, w0 = lane * per;
+            int mine = 0;
+            for (int i = 0; i < per; ++i) mine += (w0 + i < nw) ? __popcll(mask[w0 + i]) : 0;
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); incl += (lane >= o) ? v : 0; }
+            int run = incl - mine;
+            for (int i = 0; i < per; ++i)
+                if (w0 + i < nw) { pref[w0 + i] = run; run += __popcll(mask[w0 + i]); }
+            if (lane == 63) total_sh = incl;
+        }
         __syncthreads();
+        for (int r = tid; r < nw * 64; r += 1024) {
+            const unsigned long long m = mask[r >> 6];
+            if ((m >> lane) & 1ull) {
+                const int pos = base + pref[r >> 6] + __popcll(m & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = M[(size_t)(h0 + r) * stride + e];
+                S[pos] = h0 + r;
+            }
+        }
+        base += total_sh;
+        __syncthreads();                                   // the tables are rewritten by the next round
     }
-    const int n = base_sh;
-    for (int pos = n + tid; pos < H; pos += 1024) {
+    for (int pos = base + tid; pos < H; pos += 1024) {
         for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = 0.0f;
         S[pos] = -1;
     }
-    if (tid == 0) n_live[b] = n;
+    if (tid == 0) n_live[b] = base;
 }
 
 // out[b] = table[b][sel[b]] (-1 when sel[b] is outside [0, H)): compact position of a winner -> its slot
@@ -391,7 +411,12 @@ extern "C" int ph_compact_models(const float* models, int B, int H, int stride, 
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0) return PH_OK;
     if (!n_live || (H > 0 && (!models || !out || !slot)) || models == out) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(compact_models_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
+    if (stride == 9)
+        hipLaunchKernelGGL(compact_models_kernel<9>, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
+    else if (stride == 12)
+        hipLaunchKernelGGL(compact_models_kernel<12>, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
+    else
+        hipLaunchKernelGGL(compact_models_kernel<0>, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
     return ph_launch_status();
 }
 
