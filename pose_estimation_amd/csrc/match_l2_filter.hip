@@ -108,11 +108,12 @@ __device__ __forceinline__ f32x16 mfma_f16(const uint4 a, const uint4 b, const f
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// zero the per-query slot counters of the launch and compute Tmax, Qmax per pair
+// Tmax, Qmax per pair; with zero_cnt also zeroes the per-query slot counters of the launch (only needed when no filter
+// kernel follows: the filter writes the counter of every (live query, slot) itself, empty splits included)
 __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __restrict__ tnorm, const float* __restrict__ qnorm,
                                                             const int32_t* __restrict__ view_t, const int32_t* __restrict__ view_q,
                                                             const int32_t* __restrict__ n_t, const int32_t* __restrict__ n_q,
-                                                            int nq, int nt, int slots, int B,
+                                                            int nq, int nt, int slots, int B, int zero_cnt,
                                                             float* __restrict__ tqmax, int32_t* __restrict__ cnt) {
     __shared__ float red[2][4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -126,7 +127,8 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
     for (int j = tid; j < nqv; j += 256) mq = fmaxf(mq, QN[j]);
     for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = m; red[1][tid >> 6] = mq; }
-    for (size_t i = tid; i < (size_t)nq * slots; i += 256) cnt[(size_t)b * nq * slots + i] = 0;
+    if (zero_cnt)
+        for (size_t i = tid; i < (size_t)nq * slots; i += 256) cnt[(size_t)b * nq * slots + i] = 0;
     __syncthreads();
     if (tid < 2) tqmax[tid * B + b] = sqrtf(fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3])));
 }
@@ -252,7 +254,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
 
     const int t_begin = split * rows_per_split;          // a multiple of kSR
     const int t_end = min(ntv, t_begin + rows_per_split);
-    if (t_begin >= t_end) return;
+    if (t_begin >= t_end) {                              // a split beyond the pair's valid train rows: empty segments
+#pragma unroll
+        for (int ct = 0; ct < kQT; ++ct)
+            if (qw0 + ct * 32 + li < nqv) cnt[qoff[ct]] = 0;
+        return;
+    }
     const int n_tiles = (t_end - t_begin + kSR - 1) / kSR;
     const int n_prime = min(kPrimeRows / kSR, max(1, n_tiles / 8));
 
@@ -760,7 +767,7 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
     int2* list = (int2*)((char*)ws + p.off_list);
     uint4* img = (uint4*)((char*)ws + p.off_img);
     hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, norm_q, view_t, view_q, n_t, n_q, nq, nt,
-                       p.slots, B, tqmax, cnt);
+                       p.slots, B, nt > 0 ? 0 : 1, tqmax, cnt);
     if (nt > 0) {
         hipLaunchKernelGGL(l2_presplit_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, desc_t, norm_t, view_t, n_t,
                            nt, p.tiles, B, tqmax, img);
