@@ -35,6 +35,9 @@
 #ifndef PH_ABLATE
 #define PH_ABLATE 0
 #endif
+#ifndef PH_RR_UNROLL
+#define PH_RR_UNROLL 4
+#endif
 
 namespace {
 
@@ -493,9 +496,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
 }
 
 // exact contract chain: s = fma chain over k in the order 8c + {0,4,1,5,2,6,3,7}, started at -|t|^2/2
+template <int UNROLL = 8>
 __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const float4* __restrict__ t, float tn) {
     float acc = -0.5f * tn;
-#pragma unroll 8
+#pragma unroll UNROLL
     for (int c = 0; c < kDim / 8; ++c) {
         const float4 q0 = q[2 * c], q1 = q[2 * c + 1], t0 = t[2 * c], t1 = t[2 * c + 1];
         acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
@@ -506,21 +510,27 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
     return acc;
 }
 
-// Re-rank: 8 lanes per query, eight queries per wave.  The kernel is a chain of dependent memory round trips, so it is
-// organised to make them few and wide: (1) the wave's four query rows go to LDS once; (2) every lane reads its list
-// entries of all segments at once and the query's final bound (second-largest listed sA - 2e) is formed by shuffles;
-// (3) the surviving entries of all eight queries (2-3 each) are compacted into a wave queue in LDS; (4) the queued rows
-// are fetched whole, kRC at a time, by all 64 lanes (coalesced 512-byte rows, swizzled into LDS) and lane r runs the
-// exact fma chain of row r out of LDS; (5) lane 0 of each query folds the results into (best, runner-up).
-constexpr int kRL = 8;
+// Re-rank: kRL = 4 lanes per query, sixteen queries per wave (8 lanes: 418 us for the call's three small kernels, 4: 353,
+// 2: 420, benchmarks/dbg/rr_time.py).  (1) Every lane reads its list entries of all segments at once and
+// the query's final bound (second-largest listed sA - 2e) is formed by shuffles; (2) the surviving entries of all sixteen
+// queries (2-3 each) are compacted into a wave queue in LDS; (3) lane i runs the exact fma chain of queued row i, reading
+// the train row and its query's row straight from global memory (a lane walks its 512-byte row front to back, 8 chunks =
+// one cache line in flight per batch; the lanes of one query read the same query addresses); (4) the lanes of a
+// query fold the results of the pass they find under their query's number and merge at the end.
+// The chain is a dependent sequence of 128 fmas per row whatever the layout, so what counts is how many rows one pass of
+// the wave's instructions serves: with the rows staged through LDS (the previous version: 8 rows per pass, 4 KB of LDS per
+// wave for them and 4 KB for the query rows) a wave issued three passes for its ~20 rows and a quarter of all issue
+// slots of the kernel were chain instructions with 8 of 64 lanes on; now it is one pass for ~40 rows.
+#ifndef PH_RL
+#define PH_RL 4
+#endif
+constexpr int kRL = PH_RL;
 constexpr int kRQ = 64 / kRL;          // queries per wave
-constexpr int kRC = 8;                 // rows per fetch chunk (16: 224 us, 8: 202 us, 4: 235 us, 32: 477 us — LDS per wave sets the occupancy)
+constexpr int kRQueue = 128;           // queue length that triggers a flush (a typical wave queues about 20 rows in all)
 struct RerankLds {
-    float4 rows[kRC * 32];             // kRC rows x 32 chunks, chunk c of row r at r*32 + (c ^ r)
-    float4 qrow[kRQ * 32];
-    int qj[64 + kRC];
-    int qq[64 + kRC];
-    float rs[kRC];
+    int qj[kRQueue + 64];              // wave queue of candidates: train row ...
+    int qq[kRQueue + 64];              // ... and query (0 .. kRQ-1) of the wave
+    float rs[64];                      // exact scores of one pass of 64 queued rows
 };
 __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
@@ -558,11 +568,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         __builtin_amdgcn_wave_barrier();
     };
 
-    // (1) query rows -> LDS: lane (qid, sl) copies chunks sl, sl + kRL, ... of its query
-#pragma unroll
-    for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + c] = q[c];
-
-    // (2) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound.  The counts and first
+    // (1) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound.  The counts and first
     // cache lines of the first two segments (all there are unless the train rows are split) are loaded in one go and kept
     // in registers for (3).
     bool overflow = false;
@@ -623,41 +629,23 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         m1 = better ? sc : m1;
     };
 
-    // (4) + (5) for the first n queued rows
+    // (3) + (4) for the first n queued rows
+    const float4* Qw = (const float4*)(dq + ((size_t)vq * nq + min(bq * QPB + wave * kRQ, nq - 1)) * kDim);   // row of the wave's first query
     auto flush = [&](int n) {
-        for (int base = 0; base < n; base += kRC) {
-            const int k = min(kRC, n - base);
-#pragma unroll
-            for (int i = 0; i < kRC / 2; ++i) {
-                const int id = lane + 64 * i, r = id >> 5, c = id & 31;
-                if (r < k) L.rows[r * 32 + (c ^ r)] = Tt[(size_t)L.qj[base + r] * (kDim / 4) + c];
-            }
-            const float tn = (lane < k) ? TN[L.qj[base + lane]] : 0.0f;    // travels with the rows: no second round trip
-            wave_sync();
+        for (int base = 0; base < n; base += 64) {
+            const int k = min(64, n - base);
             if (lane < k) {
-                const int r = lane;
-                const float4* qr = &L.qrow[L.qq[base + r] * 32];
-                float acc = -0.5f * tn;
-#pragma unroll 4
-                for (int c = 0; c < 16; ++c) {
-                    const float4 q0 = qr[2 * c], q1 = qr[2 * c + 1];
-                    const float4 t0 = L.rows[r * 32 + ((2 * c) ^ r)], t1 = L.rows[r * 32 + ((2 * c + 1) ^ r)];
-                    acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
-                    acc = ph_fma(t0.y, q0.y, acc); acc = ph_fma(t1.y, q1.y, acc);
-                    acc = ph_fma(t0.z, q0.z, acc); acc = ph_fma(t1.z, q1.z, acc);
-                    acc = ph_fma(t0.w, q0.w, acc); acc = ph_fma(t1.w, q1.w, acc);
-                }
-                L.rs[r] = acc;
+                const int j = L.qj[base + lane], qd = L.qq[base + lane];
+                L.rs[lane] = exact_score<PH_RR_UNROLL>(Qw + (size_t)qd * (kDim / 4), Tt + (size_t)j * (kDim / 4), TN[j]);
             }
             wave_sync();
-            if (sl == 0)
-                for (int r = 0; r < k; ++r)
-                    if (L.qq[base + r] == qid) keep(L.rs[r], L.qj[base + r]);
+            for (int r = sl; r < k; r += kRL)
+                if (L.qq[base + r] == qid) keep(L.rs[r], L.qj[base + r]);
             wave_sync();
         }
     };
 
-    // (3) compaction of the surviving entries of the four queries into the wave queue
+    // (2) compaction of the surviving entries of the wave's queries into the wave queue
     int n = 0;                                             // wave-uniform queue length
     int max_slots = (live && !overflow) ? slots : 0;
     for (int w = 32; w > 0; w >>= 1) max_slots = max(max_slots, __shfl_xor(max_slots, w));
@@ -671,12 +659,10 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             L.qj[pos] = j; L.qq[pos] = qid;
         }
         n += __builtin_popcountll(m);
-        if (n >= kRC) {                                    // keep the queue within its 64 + kRC entries
+        if (n >= kRQueue) {                                // keep the queue within its kRQueue + 64 entries (long lists only)
             wave_sync();
-            const int full = n & ~(kRC - 1);
-            flush(full);
-            if (lane < n - full) { const int a = L.qj[full + lane], c2 = L.qq[full + lane]; wave_sync(); L.qj[lane] = a; L.qq[lane] = c2; }
-            n -= full;
+            flush(n);
+            n = 0;
             wave_sync();
         }
     };
@@ -708,20 +694,19 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     wave_sync();
     flush(n);
 
-    if (overflow && sl == 0) { m1 = -INFINITY; m2 = -INFINITY; bi = PH_NO_INDEX; }
+    if (overflow) { m1 = -INFINITY; m2 = -INFINITY; bi = PH_NO_INDEX; }
     if (overflow)                                          // a segment overflowed: exact scan of every row instead
         for (int j = sl; j < ntv; j += kRL) keep(exact_score(q, Tt + (size_t)j * (kDim / 4), TN[j]), j);
-    if (overflow) {                                        // butterfly over the lanes of the query
+    // butterfly over the lanes of the query: every lane holds (best, runner-up) of the rows it folded
 #pragma unroll
-        for (int w = kRL / 2; w > 0; w >>= 1) {
-            const float om1 = __shfl_xor(m1, w), om2 = __shfl_xor(m2, w);
-            const int32_t obi = __shfl_xor(bi, w);
-            const bool other = (obi >= 0) && ((om1 > m1) || (om1 == m1 && (bi < 0 || obi < bi)));
-            const float lost = other ? m1 : om1;
-            m2 = fmaxf(lost, fmaxf(m2, om2));
-            m1 = other ? om1 : m1;
-            bi = other ? obi : bi;
-        }
+    for (int w = kRL / 2; w > 0; w >>= 1) {
+        const float om1 = __shfl_xor(m1, w), om2 = __shfl_xor(m2, w);
+        const int32_t obi = __shfl_xor(bi, w);
+        const bool other = (obi >= 0) && ((om1 > m1) || (om1 == m1 && (bi < 0 || obi < bi)));
+        const float lost = other ? m1 : om1;
+        m2 = fmaxf(lost, fmaxf(m2, om2));
+        m1 = other ? om1 : m1;
+        bi = other ? obi : bi;
     }
     if (sl == 0 && qi < nq) {
         if (!live) { idx[o] = PH_NO_INDEX; d1sq[o] = INFINITY; d2sq[o] = INFINITY; return; }
