@@ -527,10 +527,16 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
 constexpr int kRL = PH_RL;
 constexpr int kRQ = 64 / kRL;          // queries per wave
 constexpr int kRQueue = 128;           // queue length that triggers a flush (a typical wave queues about 20 rows in all)
+#ifndef PH_RR_QLDS
+#define PH_RR_QLDS 1
+#endif
 struct RerankLds {
     int qj[kRQueue + 64];              // wave queue of candidates: train row ...
     int qq[kRQueue + 64];              // ... and query (0 .. kRQ-1) of the wave
     float rs[64];                      // exact scores of one pass of 64 queued rows
+#if PH_RR_QLDS
+    float4 qrow[kRQ * 32];             // the wave's query rows: query d's chunk c at d*32 + (c ^ d)
+#endif
 };
 __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
@@ -568,6 +574,12 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         __builtin_amdgcn_wave_barrier();
     };
 
+#if PH_RR_QLDS
+    // (0) the wave's query rows -> LDS (16 B per lane and instruction, the four lanes of a query side by side): the chains
+    // of a pass would otherwise ask the L1 for the same query line once per lane and chunk
+#pragma unroll
+    for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + (c ^ qid)] = q[c];
+#endif
     // (1) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound.  The counts and first
     // cache lines of the first two segments (all there are unless the train rows are split) are loaded in one go and kept
     // in registers for (3).
@@ -636,7 +648,22 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             const int k = min(64, n - base);
             if (lane < k) {
                 const int j = L.qj[base + lane], qd = L.qq[base + lane];
+#if PH_RR_QLDS
+                const float4* t = Tt + (size_t)j * (kDim / 4);
+                const float4* qr = &L.qrow[qd * 32];
+                float acc = -0.5f * TN[j];
+#pragma unroll PH_RR_UNROLL
+                for (int c = 0; c < kDim / 8; ++c) {
+                    const float4 q0 = qr[(2 * c) ^ qd], q1 = qr[(2 * c + 1) ^ qd], t0 = t[2 * c], t1 = t[2 * c + 1];
+                    acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
+                    acc = ph_fma(t0.y, q0.y, acc); acc = ph_fma(t1.y, q1.y, acc);
+                    acc = ph_fma(t0.z, q0.z, acc); acc = ph_fma(t1.z, q1.z, acc);
+                    acc = ph_fma(t0.w, q0.w, acc); acc = ph_fma(t1.w, q1.w, acc);
+                }
+                L.rs[lane] = acc;
+#else
                 L.rs[lane] = exact_score<PH_RR_UNROLL>(Qw + (size_t)qd * (kDim / 4), Tt + (size_t)j * (kDim / 4), TN[j]);
+#endif
             }
             wave_sync();
             for (int r = sl; r < k; r += kRL)
