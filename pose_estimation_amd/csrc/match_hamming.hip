@@ -14,6 +14,8 @@
 // hamming_merge_kernel merges them.
 // Earlier generations of this kernel (8 xor + 8 popcount VALU ops per pair: 16.6 ms at 28 pairs of 32 768^2; int8
 // MFMA with in-kernel expansion: 5.84 ms; this one: 4.0 ms) are in the git history.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -95,6 +97,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {    
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
+// the same copy with a scalar base address and a 32-bit per-lane byte offset: no vector address arithmetic per copy
+__device__ __forceinline__ void glds16s(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+// x of the same-numbered lane of the lower (lo) and upper (hi) half of the wave, in every lane (one VALU swap instead of
+// an LDS-pipe shuffle); callers use lo and hi symmetrically
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    lo = __uint_as_float(r.x); hi = __uint_as_float(r.y);
+}
 
 template <int QT>
 __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
@@ -159,45 +174,58 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
         // The other lane half scans the other rows of the same query.  A row can only enter the query's top-2 (ties:
         // lowest index for the best, distance only for the runner-up) if it beats the second-largest score of BOTH
         // halves' top-2 together, all from earlier rows — the tighter entry test, refreshed after every scan.
-        const float o1 = __shfl_xor(m1[ct], 32), o2 = __shfl_xor(m2[ct], 32);
-        bound[ct] = fmaxf(fminf(m1[ct], o1), fmaxf(m2[ct], o2));
+        float l1, h1, l2, h2;
+        both_halves(m1[ct], l1, h1); both_halves(m2[ct], l2, h2);
+        bound[ct] = fmaxf(fminf(l1, h1), fmaxf(l2, h2));
     };
 
     if (t_begin < t_end) {
         const int n_iter = (t_end - t_begin + kHSR - 1) / kHSR;
         const int tile0 = t_begin / kHSR;
+        // Copies: scalar base + ONE constant per-lane offset (tid * 16), LDS destination in scalar registers; the tile loop is
+        // unrolled over the three ring buffers so that every LDS read is register + immediate: no vector instruction stands
+        // between the barrier and a wave's first MFMA (match_l2_filter.hip, DESIGN.md §3a "ablation study").
+        const unsigned wave_s = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned voff = (unsigned)tid * 16u;
         auto stage = [&](int it, int buf) {
-            const uint4* src = IMG + (size_t)(tile0 + it) * kHImg;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kHImg + wave * 64));
+            const char* src = (const char*)(IMG + (size_t)(tile0 + it) * kHImg);
+            const unsigned dst = lds_addr(smem) + (unsigned)buf * (kHImg * 16u) + wave_s * 1024u;
 #pragma unroll
-            for (int u = 0; u < kHImgRows / 256; ++u) glds16(src + (wave + 4 * u) * 64 + lane, dst + 4096u * u);
-            const unsigned dst_tail = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * kHImg + kHImgRows + wave * (kHImgTail / 4)));
-            if (lane < kHImgTail / 4) glds16(src + kHImgRows + wave * (kHImgTail / 4) + lane, dst_tail);
+            for (int u = 0; u < kHImgRows / 256; ++u) glds16s(src + 4096 * u, voff, dst + 4096u * u);
+            // tail: lane l of wave w copies chunk w * (kHImgTail / 4) + l; the lane offset register carries w * 1024 too much
+            if (lane < kHImgTail / 4)
+                glds16s(src + kHImgRows * 16 + (long)wave_s * (kHImgTail / 4 * 16) - (long)wave_s * 1024, voff,
+                        lds_addr(smem) + (unsigned)buf * (kHImg * 16u) + kHImgRows * 16u + wave_s * (kHImgTail / 4 * 16u));
         };
+        unsigned aoff[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) aoff[s] = (unsigned)(li * 8 + ((2 * s + h) ^ (li & 7))) * 16u;
+        const unsigned poff = (unsigned)h * 16u;
         stage(0, 0);
         if (n_iter > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        int cur = 0, nxt2 = 2;
-        for (int it = 0; it < n_iter; ++it) {
+        auto iteration = [&](auto bufc, int it) {
+            constexpr int BUF = decltype(bufc)::value, NXT = (BUF + 2) % 3;
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const bool more = it + 2 < n_iter;
-            if (more) stage(it + 2, nxt2);
+            if (more) stage(it + 2, NXT);
+            const char* sm = (const char*)smem;
             f32x16 acc[kHSub][QT];
 #pragma unroll
             for (int sub = 0; sub < kHSub; ++sub) {
-                const float4* tneg = (const float4*)(smem + cur * kHImg + kHImgRows) + sub * (kMR / 4);
+                const unsigned base = BUF * (kHImg * 16u) + sub * (kMR * 8 * 16u);
+                const unsigned pbase = BUF * (kHImg * 16u) + kHImgRows * 16u + sub * (kMR * 4u);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 z = tneg[2 * g + h];     // rows 8g + 4h .. +3
+                    const float4 z = *(const float4*)(sm + (poff + (pbase + 32u * g)));     // rows 8g + 4h .. +3
                     acc[sub][0][4 * g + 0] = z.x; acc[sub][0][4 * g + 1] = z.y; acc[sub][0][4 * g + 2] = z.z; acc[sub][0][4 * g + 3] = z.w;
                 }
 #pragma unroll
                 for (int ct = 1; ct < QT; ++ct) acc[sub][ct] = acc[sub][0];
-                const uint4* trow = smem + cur * kHImg + sub * (kMR * 8) + li * 8;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const uint4 a4 = trow[(2 * s + h) ^ (li & 7)];
+                    const uint4 a4 = *(const uint4*)(sm + (aoff[s] + base));
                     const i32x8 a = {(int)a4.x, (int)a4.y, (int)a4.z, (int)a4.w, 0, 0, 0, 0};
 #pragma unroll
                     for (int ct = 0; ct < QT; ++ct) {
@@ -212,8 +240,11 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
             for (int sub = 0; sub < kHSub; ++sub)
 #pragma unroll
                 for (int ct = 0; ct < QT; ++ct) scan(acc[sub][ct], ct, t_begin + it * kHSR + sub * kMR);
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        };
+        for (int it = 0; it < n_iter; it += 3) {
+            iteration(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < n_iter) iteration(std::integral_constant<int, 1>{}, it + 1);
+            if (it + 2 < n_iter) iteration(std::integral_constant<int, 2>{}, it + 2);
         }
     }
 
