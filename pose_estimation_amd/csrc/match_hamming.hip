@@ -1,12 +1,16 @@
 // match_hamming.hip — brute-force 256-bit Hamming matcher, nearest + second nearest, on the matrix cores.
 // SURVEY.md §8 row a-9 (no reference code; contract in include/posehot.h).
 //
-// For 0/1 vectors  d(q, t) = |q| + |t| - 2 q.t, so the matcher is a GEMM: a descriptor bit becomes a 4-bit float
-// (e2m1: 1.0 in train rows, 2.0 in query rows, block scales 1.0) and v_mfma_scale_f32_32x32x64_f8f6f4 accumulates
-// S = 2 q.t - |t|  on top of a C operand preset to -|t| per train row — at most 256 exact products, exact in f32.
+// With the bits as +-1 (set -> +1, clear -> -1)  q.t = 256 - 2 d(q, t), so the matcher is a GEMM without norm terms: a
+// descriptor bit becomes a 4-bit float (e2m1: +1.0 = 0x2, -1.0 = 0xA, block scales 1.0) and
+// v_mfma_scale_f32_32x32x64_f8f6f4 accumulates S = q.t from a zero C operand — 256 exact products, exact in f32.
+// (The first MFMA version used 0/1 bits and S = 2 q.t - |t| with -|t| preset per train row through the C operand: those
+// presets were half of the kernel's LDS reads, and the LDS pipe — one 128-bit fragment read per MFMA at one column tile per
+// wave — is what bounds this kernel.)
 // For one query, min d <=> max S.  The accumulator has the query on the lane and 16 train rows in the lane's
 // registers (same orientation as the L2 matcher), so top-2 is an in-lane scan in increasing row order (ties -> lowest
-// index); a tile is scanned only if some lane's tile maximum beats the query's current runner-up.
+// index); a tile is scanned only if some lane's tile maximum beats the query's current runner-up.  Rows at or beyond the
+// pair's valid count (all-zero nibbles in the image: S = 0) are set to "no score" in the one staged tile they can occur in.
 //   grid = (ceil(nq / 128), splits, B), block = 256 threads = 4 waves, one 32-query column tile per wave.
 //   hamming_expand_kernel prepares the pair's train view once (LDS tile images), the matcher streams them by LDS-DMA.
 // Results travel as keys (distance << 22) + train_index, which order lexicographically by (distance, index).  When the
@@ -44,7 +48,7 @@ constexpr int kMR = 32;                           // train rows per MFMA tile
 // a lane does not matter as long as both operands are expanded by the same function (they are).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr float kNoScoreF = -1.0e9f;              // exactly representable; padded rows are all-zero, so they keep it
+constexpr float kNoScoreF = -1.0e9f;              // exactly representable, below every real score (>= -256)
 
 // 8 bits -> 8 nibbles, bit i at bit 4i
 __device__ __forceinline__ uint32_t spread8(uint32_t x) {
@@ -52,22 +56,21 @@ __device__ __forceinline__ uint32_t spread8(uint32_t x) {
     t = (t | (t << 6)) & 0x03030303u;
     return (t | (t << 3)) & 0x11111111u;
 }
-// 32 bits -> 32 e2m1 values: bit set -> 1.0 (sh = 1) or 2.0 (sh = 2), clear -> 0
-__device__ __forceinline__ uint4 expand32_fp4(uint32_t w, int sh) {
-    return make_uint4(spread8(w & 0xFFu) << sh, spread8((w >> 8) & 0xFFu) << sh, spread8((w >> 16) & 0xFFu) << sh,
-                      spread8(w >> 24) << sh);
+// 32 bits -> 32 e2m1 values: bit set -> +1.0 (0x2), clear -> -1.0 (0xA)
+__device__ __forceinline__ uint4 expand32_fp4(uint32_t w) {
+    return make_uint4(0xAAAAAAAAu ^ (spread8(w & 0xFFu) << 3), 0xAAAAAAAAu ^ (spread8((w >> 8) & 0xFFu) << 3),
+                      0xAAAAAAAAu ^ (spread8((w >> 16) & 0xFFu) << 3), 0xAAAAAAAAu ^ (spread8(w >> 24) << 3));
 }
 
 // ---- fp4 matcher with the train view expanded ONCE per pair (not once per query block: 128 blocks of a 32 768-row
 // view used to repeat the 32-bit -> 32-nibble expansion of every tile) into ready-made LDS tile images that the query
 // blocks stream with LDS-DMA: no staging registers, VALU or LDS writes in the loop (the scheme of match_l2_filter.hip).
-//   image of a staged tile (64 rows): uint4 [sub*256 + r*8 + (c ^ (r & 7))], sub = 0..1, r = 0..31, c = 16-byte chunk
-//                                     then 64 floats: -|t| per row (kNoScoreF at or beyond the pair's valid count)
+//   image of a staged tile (64 rows): uint4 [sub*256 + r*8 + (c ^ (r & 7))], sub = 0..1, r = 0..31, c = 16-byte chunk;
+//                                     rows at or beyond the pair's valid count are all-zero nibbles
 constexpr int kHSub = 2;
 constexpr int kHSR = kMR * kHSub;                       // rows per staged tile
 constexpr int kHImgRows = kHSub * kMR * 8;               // uint4
-constexpr int kHImgTail = kHSR / 4;                      // uint4
-constexpr int kHImg = kHImgRows + kHImgTail;
+constexpr int kHImg = kHImgRows;
 __global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __restrict__ dt, const int32_t* __restrict__ view_t,
                                                             const int32_t* __restrict__ n_t, int nt, int tiles,
                                                             uint4* __restrict__ img) {
@@ -82,10 +85,7 @@ __global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __r
         const int id = tid + 256 * u, row = id >> 3, part = id & 7, sub = row >> 5, r = row & 31;
         const bool ok = t0 + row < ntv;
         const uint32_t wd = ok ? T[(size_t)(t0 + row) * 8 + part] : 0u;
-        out[sub * (kMR * 8) + r * 8 + (part ^ (r & 7))] = expand32_fp4(wd, 1);
-        int pc = __popc(wd);
-        pc += __shfl_xor(pc, 1); pc += __shfl_xor(pc, 2); pc += __shfl_xor(pc, 4);
-        if (part == 0) ((float*)(out + kHImgRows))[row] = ok ? -(float)pc : kNoScoreF;
+        out[sub * (kMR * 8) + r * 8 + (part ^ (r & 7))] = ok ? expand32_fp4(wd) : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
     int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
     uint2* __restrict__ partial) {
     __shared__ uint4 smem[3 * kHImg];             // ring of three staged tiles (ONE LDS object beside the DMA target)
-    static_assert(kHImgRows % 256 == 0 && kHImgTail % 4 == 0, "staging deal");
-    constexpr int kGlds = kHImgRows / 256 + 1;    // LDS-DMA instructions per wave per staged tile
+    static_assert(kHImgRows % 256 == 0, "staging deal");
+    constexpr int kGlds = kHImgRows / 256;        // LDS-DMA instructions per wave per staged tile
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
     const int qw0 = (blockIdx.x * 4 + wave) * (32 * QT);
 
     uint4 bq[QT][4];
-    int pq[QT], bi[QT];
+    int bi[QT];
     float m1[QT], m2[QT], bound[QT];
 #pragma unroll
     for (int ct = 0; ct < QT; ++ct) {
@@ -141,11 +141,8 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
         uint4 a = make_uint4(0, 0, 0, 0), c = a;
         if (qi < nqv) { a = Q[(size_t)qi * 2]; c = Q[(size_t)qi * 2 + 1]; }
         const uint32_t w[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
-        pq[ct] = 0;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) pq[ct] += __popc(w[s]);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bq[ct][s] = expand32_fp4(h ? w[2 * s + 1] : w[2 * s], 2);
+        for (int s = 0; s < 4; ++s) bq[ct][s] = expand32_fp4(h ? w[2 * s + 1] : w[2 * s]);
         m1[ct] = kNoScoreF; m2[ct] = kNoScoreF; bound[ct] = kNoScoreF; bi[ct] = PH_NO_INDEX;
     }
 
@@ -192,15 +189,10 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
             const unsigned dst = lds_addr(smem) + (unsigned)buf * (kHImg * 16u) + wave_s * 1024u;
 #pragma unroll
             for (int u = 0; u < kHImgRows / 256; ++u) glds16s(src + 4096 * u, voff, dst + 4096u * u);
-            // tail: lane l of wave w copies chunk w * (kHImgTail / 4) + l; the lane offset register carries w * 1024 too much
-            if (lane < kHImgTail / 4)
-                glds16s(src + kHImgRows * 16 + (long)wave_s * (kHImgTail / 4 * 16) - (long)wave_s * 1024, voff,
-                        lds_addr(smem) + (unsigned)buf * (kHImg * 16u) + kHImgRows * 16u + wave_s * (kHImgTail / 4 * 16u));
         };
         unsigned aoff[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) aoff[s] = (unsigned)(li * 8 + ((2 * s + h) ^ (li & 7))) * 16u;
-        const unsigned poff = (unsigned)h * 16u;
         stage(0, 0);
         if (n_iter > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,14 +207,10 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
 #pragma unroll
             for (int sub = 0; sub < kHSub; ++sub) {
                 const unsigned base = BUF * (kHImg * 16u) + sub * (kMR * 8 * 16u);
-                const unsigned pbase = BUF * (kHImg * 16u) + kHImgRows * 16u + sub * (kMR * 4u);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 z = *(const float4*)(sm + (poff + (pbase + 32u * g)));     // rows 8g + 4h .. +3
-                    acc[sub][0][4 * g + 0] = z.x; acc[sub][0][4 * g + 1] = z.y; acc[sub][0][4 * g + 2] = z.z; acc[sub][0][4 * g + 3] = z.w;
-                }
+                for (int ct = 0; ct < QT; ++ct)
 #pragma unroll
-                for (int ct = 1; ct < QT; ++ct) acc[sub][ct] = acc[sub][0];
+                    for (int r = 0; r < 16; ++r) acc[sub][ct][r] = 0.0f;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const uint4 a4 = *(const uint4*)(sm + (aoff[s] + base));
@@ -236,10 +224,21 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
             }
             if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t0 = t_begin + it * kHSR;
+            if (t0 + kHSR > t_end) {                    // the staged tile the valid rows end in (wave-uniform, once per block)
+#pragma unroll
+                for (int sub = 0; sub < kHSub; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool pad = t0 + sub * kMR + 4 * h + (r & 3) + 8 * (r >> 2) >= t_end;
+#pragma unroll
+                        for (int ct = 0; ct < QT; ++ct) acc[sub][ct][r] = pad ? kNoScoreF : acc[sub][ct][r];
+                    }
+            }
 #pragma unroll
             for (int sub = 0; sub < kHSub; ++sub)
 #pragma unroll
-                for (int ct = 0; ct < QT; ++ct) scan(acc[sub][ct], ct, t_begin + it * kHSR + sub * kMR);
+                for (int ct = 0; ct < QT; ++ct) scan(acc[sub][ct], ct, t0 + sub * kMR);
         };
         for (int it = 0; it < n_iter; it += 3) {
             iteration(std::integral_constant<int, 0>{}, it);
@@ -261,8 +260,8 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
         if (h != 0 || qi >= nq) continue;
         uint32_t k1 = kNoKey, k2 = kNoKey;
         if (qi < nqv && nbi >= 0) {
-            k1 = ((uint32_t)(pq[ct] - (int)nm1) << kIdxBits) + (uint32_t)nbi;
-            if (nm2 != kNoScoreF) k2 = ((uint32_t)(pq[ct] - (int)nm2) << kIdxBits) + kIdxMask;
+            k1 = ((uint32_t)((256 - (int)nm1) >> 1) << kIdxBits) + (uint32_t)nbi;          // d = (256 - q.t) / 2
+            if (nm2 != kNoScoreF) k2 = ((uint32_t)((256 - (int)nm2) >> 1) << kIdxBits) + kIdxMask;
         }
         if (splits == 1) emit(k1, k2, idx, d1, d2, (size_t)b * nq + qi);
         else partial[((size_t)b * splits + split) * nq + qi] = make_uint2(k1, k2);
