@@ -112,7 +112,7 @@ __device__ __forceinline__ void both_halves(float x, float& lo, float& hi) {
 }
 
 template <int QT>
-__global__ __launch_bounds__(256, QT == 1 ? 4 : 2) void hamming_fp4_dma_kernel(
+__global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     const uint4* __restrict__ dq, const uint4* __restrict__ img, int tiles,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int splits, int rows_per_split,
@@ -273,8 +273,10 @@ struct HammingMfmaPlan { int qt, splits, rows_per_split, tiles; size_t off_img, 
 HammingMfmaPlan plan_hamming_mfma(int B, int nq, int nt) {
     HammingMfmaPlan p;
     const long target = 1024;                                  // four 4-wave blocks per CU
-    p.qt = 1;      // one column tile per wave at 4 waves per SIMD (115 VGPR): 4.0 ms where two tiles at 2 waves take 4.4 —
-                   // matrix and vector instructions of a SIMD do not overlap, more waves fill the gaps between them
+    p.qt = 2;      // two column tiles per wave at 3 waves per SIMD (<= 168 VGPR): every fragment read from LDS feeds two
+                   // MFMAs — 2.96 ms at 28 pairs of 32768^2 where one tile per wave at 4 waves per SIMD takes 3.17 (the LDS
+                   // pipe bounds the kernel: at one tile per wave it would have to deliver a 128-bit read per lane per MFMA);
+                   // before the presets were dropped and the staging cleaned up the order was the reverse (4.0 against 4.4)
     while (p.qt > 1 && (long)B * ph_ceil_div(nq, 128 * p.qt) < target) p.qt >>= 1;
     const long blocks = (long)B * ph_ceil_div(nq, 128 * p.qt);
     int s = (int)((target + blocks - 1) / blocks);
