@@ -81,7 +81,7 @@ def main():
             med, best = timeit(lambda: matching.match_hamming(tab, tab, vq, vt), args.iters)
             # the kernel runs 256 fp4 MACs per descriptor pair on the matrix cores (block-scaled fp4 MFMA = 4x the bf16 rate);
             # frac is against that peak, int8_frac against the int8 peak the previous kernel version was priced on
-            report("hamming_expand_kernel + hamming_fp4_dma_kernel<1>", f"{B} pairs {n}x{n}x256 bit", med, best,
+            report("hamming_expand_kernel + hamming_fp4_dma_kernel<2>", f"{B} pairs {n}x{n}x256 bit", med, best,
                    512.0 * n * n * B, "OP/s", MFMA_FP4_PEAK,
                    {"bound": "mfma", "hbm_frac": (2 * n * 32 + n * 12) * B / med / HBM_PEAK, "pairs_per_s": B / med,
                     "int8_frac": 512.0 * n * n * B / med / MFMA_I8_PEAK,
