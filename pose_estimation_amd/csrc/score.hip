@@ -105,7 +105,10 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
 #pragma unroll
     for (int k = 0; k < kHPW; ++k) { cnt[k] = 0; wave_live |= live[k]; }
 
-    const size_t row = (size_t)b * N;
+    __amdgpu_buffer_rsrc_t rsrc[NA];                       // the item's rows of the point arrays, valid points only
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+        rsrc[a] = __builtin_amdgcn_make_buffer_rsrc((void*)(pts.a[a] + (size_t)b * N), 0, max(p_end, 0) * 4, 0x00020000);
     int known = 0;                                         // best count of the item this wave knows of
     int32_t* lbp = Bail ? best_lb + (size_t)b * PH_BAILOUT_SLOTS : nullptr;
     int rot = (blockIdx.x * 4 + wave) & (kRep - 1);
@@ -127,14 +130,19 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ mo
             }
             if (!any_live) break;
         }
+        // Raw buffer loads: one 32-bit lane offset per chunk, the point's position inside the chunk in the instruction's
+        // immediate, reads beyond the item's valid points return 0 without touching memory (then set to NaN below) — no
+        // 64-bit vector address arithmetic, no clamping (it was ~100 of a chunk's ~1 300 vector instructions).
         float pt[kPPL][NA];
+        const unsigned voff = (unsigned)(c0 + lane) * 4u;
 #pragma unroll
-        for (int p = 0; p < kPPL; ++p) {
-            const int i = c0 + p * 64 + lane;
-            const size_t o = row + min(i, p_end - 1);
+        for (int p = 0; p < kPPL; ++p)
 #pragma unroll
-            for (int a = 0; a < NA; ++a) pt[p][a] = pts.a[a][o];
-            pt[p][0] = (i < p_end) ? pt[p][0] : NAN;        // a NaN coordinate never passes '<'
+            for (int a = 0; a < NA; ++a)
+                pt[p][a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc[a], voff + 256u * p, 0, 0));
+        if (c0 + 64 * kPPL > p_end) {                       // the item's last chunk (wave-uniform)
+#pragma unroll
+            for (int p = 0; p < kPPL; ++p) pt[p][0] = (c0 + p * 64 + lane < p_end) ? pt[p][0] : NAN;   // NaN never passes '<'
         }
 #pragma unroll
         for (int k = 0; k < kHPW; ++k) {
