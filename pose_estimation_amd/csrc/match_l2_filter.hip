@@ -55,7 +55,7 @@ constexpr int kNS = kDim / 16;  // MFMA k-steps per row
 constexpr int kCapH = 32;      // list entries per (query, split, lane half)
 constexpr int kBlocksPerCU = 2;
 constexpr int kDepth = 2;         // staged tiles copied ahead of the one being worked on (3: same time; 4: slower)
-constexpr int kPrimeRows = 512;   // rows of the priming pass (per split)
+constexpr int kPrimeRows = 512;   // rows of the priming pass (per split); 128 and 256 time the same, 1024 is 5 % slower
 
 // ---- per-pair scales and the error band (one definition for the three kernels) -------------------------------------
 struct PairScale {
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     };
 
     // (3) + (4) for the first n queued rows
-    const float4* Qw = (const float4*)(dq + ((size_t)vq * nq + min(bq * QPB + wave * kRQ, nq - 1)) * kDim);   // row of the wave's first query
+    [[maybe_unused]] const float4* Qw = (const float4*)(dq + ((size_t)vq * nq + min(bq * QPB + wave * kRQ, nq - 1)) * kDim);   // row of the wave's first query
     auto flush = [&](int n) {
         for (int base = 0; base < n; base += 64) {
             const int k = min(64, n - base);
