@@ -63,6 +63,23 @@ def test_hamming_batched_views_and_ragged(device):
     assert keep[3].sum() == 0 and keep[4].sum() == 0
 
 
+def test_hamming_far_rows_beat_padding(device):
+    """Rows beyond the valid count are zero nibbles in the tile image (score 0 = distance 128): every real row here is
+    FARTHER than that (distance 200-256), in the staged tile the valid rows end in and with a ragged count."""
+    rng = np.random.default_rng(77)
+    nt, nq = 200, 70
+    t = np.zeros((nt, 32), np.uint8)
+    t[rng.random((nt, 32)) < 0.05] = 1                    # a few set bits
+    q = np.full((nq, 32), 255, np.uint8)
+    q[rng.random((nq, 32)) < 0.05] = 254
+    for n_t in (1, 63, 65, 130, 200):
+        idx, d1, d2 = matching.match_hamming(_t(q[None], device), _t(t[None], device), n_t=_t(np.array([n_t], np.int32), device))
+        ri, r1, r2 = orc.match_hamming_top2(q, t[:n_t])
+        assert r1.min() > 128
+        assert np.array_equal(idx.cpu().numpy()[0], ri) and np.array_equal(d1.cpu().numpy()[0], r1)
+        assert np.array_equal(d2.cpu().numpy()[0], r2)
+
+
 def test_hamming_empty_train(device):
     q = np.zeros((1, 10, 32), np.uint8)
     t = np.zeros((1, 0, 32), np.uint8)
