@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
     const bool ok = i < nv;
+    if (blockIdx.x * 256 + (int)(threadIdx.x & ~63u) >= nv) return;     // a wave beyond the item's valid points (wave-uniform):
+                                                                        // the arrays are sized for the capacity, not the count
+    if (!XYZ && mask && ((blockIdx.x * 256 + (int)(threadIdx.x & ~63u)) >> 6) < (N + 63) / 64 &&
+        mask[(size_t)b * ((N + 63) / 64) + ((blockIdx.x * 256 + (int)(threadIdx.x & ~63u)) >> 6)] == 0ull)
+        return;                                                         // vote only, and none of the wave's 64 points is selected
     const float* pa = P1 + ((size_t)b * C + c) * 12;
     const float* pb = P2 + ((size_t)b * C + c) * 12;
     float Pa[12], Pb[12];
@@ -207,6 +212,7 @@ __global__ __launch_bounds__(1024) void compact_models_kernel(const float* __res
                                                              float* __restrict__ out, int32_t* __restrict__ slot,
                                                              int32_t* __restrict__ n_live) {
     const int stride = STRIDE > 0 ? STRIDE : stride_rt;
+    constexpr int kUnroll = STRIDE > 0 ? STRIDE : 1;
     __shared__ unsigned long long mask[1024];
     __shared__ int pref[1024];
     __shared__ int total_sh;
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(1024) void compact_models_kernel(const float* __res
         for (int r = tid; r < nw * 64; r += 1024) {
             uint32_t any = 0;
             if (r < span) {
-#pragma unroll
+#pragma unroll kUnroll
                 for (int e = 0; e < stride; ++e) any |= __float_as_uint(M[(size_t)(h0 + r) * stride + e]) << 1;      // +-0 -> 0
             }
             const unsigned long long votes = __ballot(any != 0u);
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(1024) void compact_models_kernel(const float* __res
             const unsigned long long m = mask[r >> 6];
             if ((m >> lane) & 1ull) {
                 const int pos = base + pref[r >> 6] + __popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll
+#pragma unroll kUnroll
                 for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = M[(size_t)(h0 + r) * stride + e];
                 S[pos] = h0 + r;
             }
