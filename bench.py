@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--precision", type=int, default=1,
                     help="L2 matcher algorithm (identical bit-exact outputs): 0 = every score on f32 MFMA, "
                          "1 = fp16 MFMA candidate filter + exact f32 re-rank")
+    ap.add_argument("--unfused", action="store_true",
+                    help="ph_match_l2_top2 + ph_ratio_filter_l2 instead of ph_match_l2_ratio (same idx / keep)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the batches alternate over: with 2, the latency-bound RANSAC stages of one batch "
                          "run beside the MFMA-bound matcher of the next")
@@ -232,11 +234,16 @@ def main():
     slot_bufs = [{k: torch.empty_like(batch[k]) for k in keys} for _ in range(max(args.streams, 1))] if args.h2d else None
     cur = {"buf": batch}
 
+    fused = args.precision == 1 and not args.unfused
+
     def match():
         b = cur["buf"]
         nq = matching.row_sqnorm(b["desc_q"])
         nt = matching.row_sqnorm(b["desc_t"])
         k = state["step"]
+        if fused:                  # matching + ratio test in one call: same idx / keep, exact re-scores only where needed
+            return (*matching.match_l2_ratio(b["desc_q"], b["desc_t"], 0.75, norm_q=nq, norm_t=nt,
+                                             kernel_events=kev[k] if state["timed"] else None), "l2_keep")
         r = matching.match_l2(b["desc_q"], b["desc_t"], norm_q=nq, norm_t=nt, precision=args.precision,
                               kernel_events=kev[k] if state["timed"] else None)
         return (*r, "l2")
@@ -346,7 +353,10 @@ def main():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
-        matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq_, norm_t=nt_, precision=args.precision, kernel_events=pr)
+        if fused:
+            matching.match_l2_ratio(batch["desc_q"], batch["desc_t"], 0.75, norm_q=nq_, norm_t=nt_, kernel_events=pr)
+        else:
+            matching.match_l2(batch["desc_q"], batch["desc_t"], norm_q=nq_, norm_t=nt_, precision=args.precision, kernel_events=pr)
         b.record()
         torch.cuda.synchronize()
         iso_k.append(hev.elapsed_ms(pr) * 1e3)
@@ -366,7 +376,8 @@ def main():
         "contended_kernel_us": contended_us, "contended_frac": flops / (contended_us * 1e-6) / 1e12 / peak,
         "contended_note": f"the same kernel inside the timed region, {args.streams} stream(s): other batches' kernels share the CUs",
         "matcher_call_us": call_us, "matcher_call_frac": flops / (call_us * 1e-6) / 1e12 / peak,
-        "matcher_call": "ph_match_l2_top2 = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel"
+        "matcher_call": ("ph_match_l2_ratio" if fused else "ph_match_l2_top2") +
+                        " = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel"
                         if args.precision == 1 else "ph_match_l2_top2 = l2_top2_f32_kernel<128>",
         "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
         "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0)"}
@@ -392,7 +403,7 @@ def main():
             "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
                                    ">= 4096 essential-matrix hypotheses (real models) per pair", "pairs_per_step_per_gpu": P,
                        "features": N_FEAT, "dim": DIM, "hypotheses": real_per_pair, "hypothesis_slots": 10 * S,
-                       "minimal_samples": S, "ratio": 0.75, "threshold_px": THR_PX, "scoring": "bail-out",
+                       "minimal_samples": S, "ratio": 0.75, "matcher": "ph_match_l2_ratio (matching + ratio test, exact re-scores only where the approximate scores do not decide)" if fused else "ph_match_l2_top2 + ph_ratio_filter_l2", "threshold_px": THR_PX, "scoring": "bail-out",
                        "refine": "none" if args.no_refine else f"device LM, {pipeline.REFINE_ITERS} iterations, Sampson cost truncated at {pipeline.REFINE_TRUNC:g} x threshold",
                        "streams": args.streams, "decompose": args.decompose,
                        "inputs": "pinned host memory, copied over PCIe inside every step (NOT the headline)" if args.h2d else "resident in HBM",

@@ -108,6 +108,21 @@ int ph_match_l2_top2_timed(const float* desc_q, const float* desc_t,
                            int32_t* idx, float* d1sq, float* d2sq,
                            void* ws, size_t ws_bytes, void* stream, void* ev_begin, void* ev_end);
 
+/* ph_match_l2_ratio: matching and ratio test in one call (north_star 1: "descriptor matching + ratio test"; no reference
+ * counterpart).  idx and keep are, bit for bit, what ph_match_l2_top2(precision = PH_PRECISION_F16_RERANK) followed by
+ * ph_ratio_filter_l2(ratio) write — but a query whose best row and whose ratio decision already follow from the candidate
+ * filter's approximate scores and their proven error band is never re-scored exactly (a planted match wins by far, a
+ * non-match fails by far: nine queries of ten); the others take the exact path.  The distances themselves are not returned.
+ * dim = 128 only; workspace as for ph_match_l2_top2 with that precision; ev_begin / ev_end as in ph_match_l2_top2_timed
+ * (NULL = no events). */
+int ph_match_l2_ratio(const float* desc_q, const float* desc_t,
+                      const float* norm_q, const float* norm_t,
+                      const int32_t* view_q, const int32_t* view_t,
+                      const int32_t* n_q, const int32_t* n_t,
+                      int B, int nq, int nt, int dim, float ratio,
+                      int32_t* idx, int32_t* keep,
+                      void* ws, size_t ws_bytes, void* stream, void* ev_begin, void* ev_end);
+
 /* Lowe ratio test, strict '<':  keep[i] = idx[i] >= 0 && second exists && d1 < ratio * d2.
  * Hamming form compares d1 < ratio*d2 in f32; L2 form takes SQUARED distances and compares
  * d1sq < ratio^2 * d2sq (== d1 < ratio*d2 on true distances).  n = B*nq elements. */

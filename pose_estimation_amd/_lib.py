@@ -42,6 +42,7 @@ SIGNATURES = {
     "ph_row_sqnorm": (_i, [_p, _i64, _i, _p, _p]),
     "ph_match_l2_top2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "ph_match_l2_top2_timed": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p, _p, _p]),
+    "ph_match_l2_ratio": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _p, _p, _sz, _p, _p, _p]),
     "ph_ratio_filter_hamming": (_i, [_p, _p, _p, _i64, _f, _p, _p]),
     "ph_ratio_filter_l2": (_i, [_p, _p, _p, _i64, _f, _p, _p]),
     "ph_compact_matches": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),

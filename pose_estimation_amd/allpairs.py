@@ -30,7 +30,8 @@ class AllPairs:
         t = torch.as_tensor(np.ascontiguousarray(vj), dtype=torch.int32).to(dev, non_blocking=True)
         key = ids.to(torch.int32).to(dev, non_blocking=True)
         if self.f32:
-            match = lambda: (*matching.match_l2(self.desc, self.desc, q, t, norm_q=self.norms, norm_t=self.norms), "l2")
+            match = lambda: (*matching.match_l2_ratio(self.desc, self.desc, self.ratio, q, t, norm_q=self.norms,
+                                                      norm_t=self.norms), "l2_keep")
         else:
             match = lambda: (*matching.match_hamming(self.desc, self.desc, q, t), "hamming")
         out = pipeline.relative_pose_batch(match, self.kp, self.kp, q, t, None, self.thr_sq, ratio=self.ratio,

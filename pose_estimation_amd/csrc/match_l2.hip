@@ -365,6 +365,25 @@ extern "C" int ph_match_l2_top2(const float* desc_q, const float* desc_t,
                                   d2sq, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
+extern "C" int ph_match_l2_ratio(const float* desc_q, const float* desc_t,
+                                 const float* norm_q, const float* norm_t,
+                                 const int32_t* view_q, const int32_t* view_t,
+                                 const int32_t* n_q, const int32_t* n_t,
+                                 int B, int nq, int nt, int dim, float ratio,
+                                 int32_t* idx, int32_t* keep,
+                                 void* ws, size_t ws_bytes, void* stream, void* ev_begin, void* ev_end) {
+    if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
+    if (dim != 128) return PH_ERR_UNSUPPORTED;             // the fused path is the fp16 filter's (dim 128)
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0 || nq == 0) return PH_OK;
+    if (!desc_q || !norm_q || !idx || !keep || (nt > 0 && (!desc_t || !norm_t))) return PH_ERR_INVALID_ARG;
+    if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
+    const L2FilterPlan fp = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
+    if (!ws || ws_bytes < fp.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
+    return launch_l2_filter(desc_q, desc_t, norm_q, norm_t, view_q, view_t, n_q, n_t, B, nq, nt, idx, nullptr, nullptr, ws,
+                            (hipStream_t)stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end, ratio * ratio, keep);
+}
+
 extern "C" int ph_ratio_filter_l2(const int32_t* idx, const float* d1sq, const float* d2sq, int64_t n, float ratio,
                                   int32_t* keep, void* stream) {
     if (n < 0) return PH_ERR_INVALID_ARG;

@@ -538,13 +538,22 @@ struct RerankLds {
     float4 qrow[kRQ * 32];             // the wave's query rows: query d's chunk c at d*32 + (c ^ d)
 #endif
 };
+// FUSE = the ratio test in the same kernel (ph_match_l2_ratio): outputs idx and keep = what ph_match_l2_top2 followed by
+// ph_ratio_filter_l2 give, bit for bit, but a query whose answer already follows from the APPROXIMATE scores skips the exact
+// chains altogether.  With a(1) >= a(2) the two largest listed approximate scores (unscaled) and e the filter's error bound,
+// the exact best and runner-up scores lie in [a(1) - e, a(1) + e] and [a(2) - e, a(2) + e]; if a(1) - a(2) > 2e the best row is
+// the row of a(1), uniquely; and d = max(0, |q|^2 - 2 m) turns the two intervals into intervals of d1sq and d2sq (widened by
+// 2^-20 relative for the float32 roundings of the contract's own fma and product and of this arithmetic).  If these decide
+// d1sq < r2 * d2sq one way or the other the query is done — nine of ten are: a planted match wins by far, a non-match
+// fails by far; the others take the exact path, so the outputs never differ from the two-kernel path.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t, int B, int nq, int nt,
     const float* __restrict__ tnorm, const float* __restrict__ qnorm,
     const float* __restrict__ tqmax, const int32_t* __restrict__ cnt, const int2* __restrict__ list, int slots,
-    int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq) {
+    int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq, float r2, int32_t* __restrict__ keep_out) {
     __shared__ RerankLds lds[4];
     // blocks of one pair share one residue of the block id mod 8 (one XCD, one L2 for the pair's train rows)
     constexpr int QPB = 256 / kRL;
@@ -574,12 +583,6 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         __builtin_amdgcn_wave_barrier();
     };
 
-#if PH_RR_QLDS
-    // (0) the wave's query rows -> LDS (16 B per lane and instruction, the four lanes of a query side by side): the chains
-    // of a pass would otherwise ask the L1 for the same query line once per lane and chunk
-#pragma unroll
-    for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + (c ^ qid)] = q[c];
-#endif
     // (1) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound.  The counts and first
     // cache lines of the first two segments (all there are unless the train rows are split) are loaded in one go and kept
     // in registers for (3).
@@ -588,7 +591,11 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     constexpr int kE = 16 / kRL;                           // entries per lane in the first cache line of a segment
     int cn[2] = {0, 0};
     int2 ent[2][kE];
-    auto bump = [&](float v) { p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v); };
+    int j1 = PH_NO_INDEX;                                  // FUSE: train row of the largest listed approximate score
+    auto bump = [&](float v, int jrow) {
+        if (FUSE) j1 = (v > p1) ? jrow : j1;
+        p2 = __builtin_amdgcn_fmed3f(p1, p2, v); p1 = fmaxf(p1, v);
+    };
     if (live) {
 #pragma unroll
         for (int slot = 0; slot < 2; ++slot) {             // slots = 2 * splits >= 2
@@ -601,9 +608,11 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             overflow |= cn[slot] > kCapH;
 #pragma unroll
             for (int k = 0; k < kE; ++k)
-                if (sl + kRL * k < cn[slot]) bump(__int_as_float(ent[slot][k].y));
-            for (int k = sl + 16; k < cn[slot] && k < kCapH; k += kRL)    // second cache line: rarely used
-                bump(__int_as_float(list[(o * slots + slot) * kCapH + k].y));
+                if (sl + kRL * k < cn[slot]) bump(__int_as_float(ent[slot][k].y), ent[slot][k].x + 4 * (slot & 1));
+            for (int k = sl + 16; k < cn[slot] && k < kCapH; k += kRL) {  // second cache line: rarely used
+                const int2 e2 = list[(o * slots + slot) * kCapH + k];
+                bump(__int_as_float(e2.y), e2.x + 4 * (slot & 1));
+            }
         }
         for (int slot = 2; slot < slots; ++slot) {
             const int c = cnt[o * slots + slot];
@@ -613,13 +622,17 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             for (int k = 0; k < kE; ++k) e[k] = list[(o * slots + slot) * kCapH + sl + kRL * k];   // issued with the count
 #pragma unroll
             for (int k = 0; k < kE; ++k)
-                if (sl + kRL * k < c) bump(__int_as_float(e[k].y));
-            for (int k = sl + 16; k < c && k < kCapH; k += kRL) bump(__int_as_float(list[(o * slots + slot) * kCapH + k].y));
+                if (sl + kRL * k < c) bump(__int_as_float(e[k].y), e[k].x + 4 * (slot & 1));
+            for (int k = sl + 16; k < c && k < kCapH; k += kRL) {
+                const int2 e2 = list[(o * slots + slot) * kCapH + k];
+                bump(__int_as_float(e2.y), e2.x + 4 * (slot & 1));
+            }
         }
     }
 #pragma unroll
     for (int w = kRL / 2; w > 0; w >>= 1) {
         const float o1 = __shfl_xor(p1, w), o2 = __shfl_xor(p2, w);
+        if (FUSE) { const int oj = __shfl_xor(j1, w); j1 = (o1 > p1) ? oj : j1; }
         p2 = fmaxf(fminf(p1, o1), fmaxf(p2, o2));
         p1 = fmaxf(p1, o1);
         overflow |= (bool)__shfl_xor((int)overflow, w);
@@ -629,8 +642,28 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     // the exact top-2: typically 2-3 of the ~11 listed rows.
     const float Tm = tqmax[b], Qm = tqmax[B + b];
     const PairScale sc = pair_scale(Tm, Qm);
-    const float bound = p2 - band2_scaled(qnorm[(size_t)vq * nq + min(qi, nq - 1)], Tm, Qm, sc.s);
+    const float qn_i = qnorm[(size_t)vq * nq + min(qi, nq - 1)];
+    const float band = band2_scaled(qn_i, Tm, Qm, sc.s);   // 2e, scaled
+    const float bound = p2 - band;
     overflow |= sc.bad;                                    // wave-uniform per pair: the lists of such a pair are not used
+    bool decided = false, decided_keep = false;            // FUSE: the query's idx and keep follow from the approximate scores
+    const bool has1 = p1 > -INFINITY, has2 = p2 > -INFINITY;                    // no arithmetic on infinities below
+    if (FUSE && live && !overflow && has1 && (!has2 || (p1 - p2) > band)) {     // the row of a(1) is the exact best
+        if (!has2) {                                       // one valid train row: no runner-up, the ratio test fails
+            decided = true;
+        } else {
+            const float inv_s = 1.0f / sc.s;               // a power of two
+            const float a1u = p1 * inv_s, a2u = p2 * inv_s, e2 = band * inv_s;             // e2 = 2e, unscaled
+            const float w1 = e2 + 9.5367431640625e-7f * (fabsf(qn_i) + 2.0f * fabsf(a1u) + e2);   // 2e + 2^-20 (...)
+            const float w2 = e2 + 9.5367431640625e-7f * (fabsf(qn_i) + 2.0f * fabsf(a2u) + e2);
+            const float c1 = ph_fma(-2.0f, a1u, qn_i), c2 = ph_fma(-2.0f, a2u, qn_i);
+            const float d1_hi = fmaxf(0.0f, c1 + w1), d1_lo = fmaxf(0.0f, c1 - w1);
+            const float d2_hi = fmaxf(0.0f, c2 + w2), d2_lo = fmaxf(0.0f, c2 - w2);
+            const float rhs_lo = r2 * d2_lo * (1.0f - 9.5367431640625e-7f), rhs_hi = r2 * d2_hi * (1.0f + 9.5367431640625e-7f);
+            if (d1_hi < rhs_lo) { decided = true; decided_keep = true; }
+            else if (d1_lo > rhs_hi) decided = true;
+        }
+    }
 
     float m1 = -INFINITY, m2 = -INFINITY;
     int32_t bi = PH_NO_INDEX;
@@ -674,7 +707,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
 
     // (2) compaction of the surviving entries of the wave's queries into the wave queue
     int n = 0;                                             // wave-uniform queue length
-    int max_slots = (live && !overflow) ? slots : 0;
+    int max_slots = (live && !overflow && !decided) ? slots : 0;
     for (int w = 32; w > 0; w >>= 1) max_slots = max(max_slots, __shfl_xor(max_slots, w));
     wave_sync();
     // one candidate row per lane (or -1) -> wave queue; flushes whole chunks when the queue reaches kRC entries
@@ -693,7 +726,16 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             wave_sync();
         }
     };
-    const bool use = live && !overflow;
+    const bool use = live && !overflow && !decided;
+#if PH_RR_QLDS
+    // the query rows of the queries that need exact scores -> LDS (16 B per lane and instruction, the four lanes of a query
+    // side by side): the chains of a pass would otherwise ask the L1 for the same query line once per lane and chunk.
+    // (Issued here, after the lists were read: a decided query of the fused kernel never touches its 512-byte row.)
+    if (use) {
+#pragma unroll
+        for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + (c ^ qid)] = q[c];
+    }
+#endif
     auto from_memory = [&](int slot, int pass) {
         int j = -1;
         if (use) {
@@ -736,11 +778,17 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         bi = other ? obi : bi;
     }
     if (sl == 0 && qi < nq) {
-        if (!live) { idx[o] = PH_NO_INDEX; d1sq[o] = INFINITY; d2sq[o] = INFINITY; return; }
         const float qn = qnorm[(size_t)vq * nq + qi];
-        idx[o] = bi;
-        d1sq[o] = (bi >= 0) ? fmaxf(0.0f, ph_fma(-2.0f, m1, qn)) : INFINITY;
-        d2sq[o] = (m2 > -INFINITY) ? fmaxf(0.0f, ph_fma(-2.0f, m2, qn)) : INFINITY;
+        const float d1 = (bi >= 0) ? fmaxf(0.0f, ph_fma(-2.0f, m1, qn)) : INFINITY;
+        const float d2 = (m2 > -INFINITY) ? fmaxf(0.0f, ph_fma(-2.0f, m2, qn)) : INFINITY;
+        if (FUSE) {
+            if (!live) { idx[o] = PH_NO_INDEX; keep_out[o] = 0; }
+            else if (decided) { idx[o] = j1; keep_out[o] = decided_keep ? 1 : 0; }
+            else { idx[o] = bi; keep_out[o] = (bi >= 0 && d2 < INFINITY && d1 < r2 * d2) ? 1 : 0; }   // ph_ratio_filter_l2's test
+        } else {
+            if (!live) { idx[o] = PH_NO_INDEX; d1sq[o] = INFINITY; d2sq[o] = INFINITY; return; }
+            idx[o] = bi; d1sq[o] = d1; d2sq[o] = d2;
+        }
     }
 }
 
@@ -772,7 +820,7 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
 int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm_q, const float* norm_t,
                      const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
                      int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st,
-                     hipEvent_t ev_begin, hipEvent_t ev_end) {
+                     hipEvent_t ev_begin, hipEvent_t ev_end, float ratio_sq, int32_t* keep) {
     const L2FilterPlan p = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
     float* tqmax = (float*)ws;                                   // Tmax[B] | Qmax[B]
     int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
@@ -791,7 +839,12 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
         if (ev_end && hipEventRecord(ev_end, st) != hipSuccess) return PH_ERR_LAUNCH;
     }
     const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
-    hipLaunchKernelGGL(l2_rerank_kernel, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
-                       view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tqmax, cnt, list, p.slots, idx, d1sq, d2sq);
+    if (keep)
+        hipLaunchKernelGGL(l2_rerank_kernel<true>, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                           view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tqmax, cnt, list, p.slots, idx, d1sq, d2sq, ratio_sq, keep);
+    else
+        hipLaunchKernelGGL(l2_rerank_kernel<false>, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                           view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tqmax, cnt, list, p.slots, idx, d1sq, d2sq, 0.0f,
+                           (int32_t*)nullptr);
     return ph_launch_status();
 }

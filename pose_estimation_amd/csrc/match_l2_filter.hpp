@@ -15,4 +15,5 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt);
 int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm_q, const float* norm_t,
                      const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
                      int B, int nq, int nt, int32_t* idx, float* d1sq, float* d2sq, void* ws, hipStream_t st,
-                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);   // optional: bracket l2_filter_kernel alone
+                     hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,    // optional: bracket l2_filter_kernel alone
+                     float ratio_sq = 0.0f, int32_t* keep = nullptr);               // keep != NULL: fused ratio test, d1sq / d2sq unused

@@ -133,6 +133,47 @@ def ratio_filter_hamming(idx, d1, d2, ratio=0.75):
     return keep
 
 
+def match_l2_ratio(desc_q, desc_t, ratio, view_q=None, view_t=None, n_q=None, n_t=None, norm_q=None, norm_t=None,
+                   kernel_events=None):
+    """Squared-L2 matching and Lowe's ratio test in one call (``ph_match_l2_ratio``).  Returns (idx int32, keep int32), each
+    ``[B, nq]`` — bit for bit what ``match_l2`` (default precision) followed by ``ratio_filter_l2`` return, without the
+    distances: a query whose best row and ratio decision already follow from the candidate filter's approximate scores is
+    never re-scored exactly.  dim = 128 only."""
+    lib = L.load()
+    desc_q = L.dev(desc_q, torch.float32, "desc_q")
+    desc_t = L.dev(desc_t, torch.float32, "desc_t")
+    if desc_q.dim() != 3 or desc_t.dim() != 3:
+        raise ValueError("descriptor tables must be [V, n, dim]")
+    nq, nt, dim = desc_q.shape[1], desc_t.shape[1], desc_q.shape[2]
+    if desc_t.shape[2] != dim:
+        raise ValueError("query and train descriptors differ in width")
+    B, view_q = _views(desc_q, view_q, "view_q")
+    Bt, view_t = _views(desc_t, view_t, "view_t")
+    if B != Bt:
+        raise ValueError(f"pair lists differ in length: {B} vs {Bt}")
+    n_q, n_t = L.opt_i32(n_q, B, "n_q"), L.opt_i32(n_t, B, "n_t")
+    dev = desc_q.device
+    norm_q = row_sqnorm(desc_q) if norm_q is None else L.dev(norm_q, torch.float32, "norm_q")
+    norm_t = (norm_q if desc_t is desc_q else row_sqnorm(desc_t)) if norm_t is None else L.dev(norm_t, torch.float32, "norm_t")
+    idx = torch.empty((B, nq), dtype=torch.int32, device=dev)
+    keep = torch.empty((B, nq), dtype=torch.int32, device=dev)
+    ev = kernel_events if kernel_events is not None else (None, None)
+    for s, e in _chunks(B):
+        nb = e - s
+        wsb = lib.ph_match_l2_ws_bytes(nb, nq, nt, dim, int(L.PRECISION_F16_RERANK))
+        ws = L.workspace(wsb, dev)
+        sl = lambda t: None if t is None else t[s:e]
+        q = desc_q if view_q is not None else desc_q[s:e]
+        t = desc_t if view_t is not None else desc_t[s:e]
+        qn = norm_q if view_q is not None else norm_q[s:e]
+        tn = norm_t if view_t is not None else norm_t[s:e]
+        L.check(lib.ph_match_l2_ratio(L.ptr(q), L.ptr(t), L.ptr(qn), L.ptr(tn), L.ptr(sl(view_q)), L.ptr(sl(view_t)),
+                                      L.ptr(sl(n_q)), L.ptr(sl(n_t)), nb, nq, nt, dim, float(ratio),
+                                      L.ptr(idx[s:e]), L.ptr(keep[s:e]), L.ptr(ws), wsb, L.stream_ptr(), ev[0], ev[1]),
+                "ph_match_l2_ratio")
+    return idx, keep
+
+
 def ratio_filter_l2(idx, d1sq, d2sq, ratio=0.75):
     """keep = second exists and d1sq < ratio^2*d2sq (strict; == ratio test on true distances)."""
     lib = L.load()

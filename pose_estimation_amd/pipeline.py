@@ -53,7 +53,8 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     """Everything up to the inlier mask, plus (decompose="host") an asynchronous copy of the winning E of every pair.
 
     match: callable returning (idx, d1, d2, kind) with kind "l2" or "hamming",
-           e.g. ``lambda: (*matching.match_l2(...), "l2")``.
+           e.g. ``lambda: (*matching.match_l2(...), "l2")`` — or (idx, keep, "l2_keep") when the ratio test was already
+           applied at `ratio` by the matcher (``matching.match_l2_ratio``: same idx and keep, fewer exact re-scores).
     kp_q/kp_t: [V, n, 2] normalised keypoints; view_q/view_t: int32 [B] (device) or None.
     E_hyp: [B, H, 9] float32 device tensor of essential-matrix hypotheses, or None: then they are
            generated on the device from `n_samples` Philox-drawn minimal samples of the pair's own
@@ -63,8 +64,12 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     item_key: per-pair Philox keys (int tensor [B], e.g. global pair ids) so that a pair draws the same minimal
            samples in whatever batch slot, chunk or rank it is processed; None = position in the batch.
     """
-    idx, d1, d2, kind = match()
-    keep = (matching.ratio_filter_l2 if kind == "l2" else matching.ratio_filter_hamming)(idx, d1, d2, ratio)
+    r = match()
+    if r[-1] == "l2_keep":
+        idx, keep = r[0], r[1]
+    else:
+        idx, d1, d2, kind = r
+        keep = (matching.ratio_filter_l2 if kind == "l2" else matching.ratio_filter_hamming)(idx, d1, d2, ratio)
     m = matching.compact_matches(idx, keep, kp_q, kp_t, view_q, view_t, want_indices=False)
     pts = (m["x1"], m["y1"], m["x2"], m["y2"])
     extra = {}
