@@ -1,6 +1,8 @@
 """ph_match_l2_ratio (matching + ratio test in one call, exact chains skipped where the approximate scores decide) against
 the two-call path it must equal bit for bit: ph_match_l2_top2 (bit-exact to the oracle, tests/test_gpu_matching.py) followed
 by ph_ratio_filter_l2."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -40,7 +42,10 @@ def test_fused_full_size_and_keep_fraction(device):
     assert 0.4 < keep.mean() < 0.8
 
 
-@pytest.mark.parametrize("seed", range(10))
+_MORE = int(os.environ.get("POSEHOT_FUZZ_SEEDS", "0"))      # extra seeds for a one-off soak run
+
+
+@pytest.mark.parametrize("seed", range(10 + _MORE))
 def test_fused_fuzz(device, seed):
     """Random shapes, ragged counts, shared view tables, duplicates (exact ties), near ties, signed data, scales."""
     rng = np.random.default_rng(9100 + seed)
