@@ -125,9 +125,22 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const float* TN = tnorm + (size_t)vt * nt;
     const float* QN = qnorm + (size_t)vq * nq;
+    // eight independent loads in flight per thread and array (one load per trip made the kernel a chain of 32 memory round trips)
     float m = 0.0f, mq = 0.0f;
-    for (int j = tid; j < ntv; j += 256) m = fmaxf(m, TN[j]);
-    for (int j = tid; j < nqv; j += 256) mq = fmaxf(mq, QN[j]);
+    for (int j0 = 0; j0 < ntv; j0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + 256 * u + tid; v[u] = (j < ntv) ? TN[j] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+    }
+    for (int j0 = 0; j0 < nqv; j0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int j = j0 + 256 * u + tid; v[u] = (j < nqv) ? QN[j] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mq = fmaxf(mq, v[u]);
+    }
     for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); mq = fmaxf(mq, __shfl_xor(mq, o)); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = m; red[1][tid >> 6] = mq; }
     if (zero_cnt)

@@ -204,10 +204,18 @@ __global__ __launch_bounds__(256) void select_best_kernel(const int32_t* __restr
     __shared__ unsigned long long red[4];
     const int b = blockIdx.x;
     unsigned long long best = 0;
-    for (int hyp = threadIdx.x; hyp < H; hyp += 256) {
-        const unsigned long long key = ((unsigned long long)(uint32_t)max(count[(size_t)b * H + hyp], 0) << 32) |
-                                       (uint32_t)(0xffffffffu - (uint32_t)hyp);
-        best = key > best ? key : best;
+    for (int h0 = 0; h0 < H; h0 += 256 * 8) {               // eight loads in flight per thread
+        int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int hyp = h0 + 256 * u + (int)threadIdx.x; c[u] = (hyp < H) ? count[(size_t)b * H + hyp] : -1; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int hyp = h0 + 256 * u + (int)threadIdx.x;
+            if (hyp < H) {
+                const unsigned long long key = ((unsigned long long)(uint32_t)max(c[u], 0) << 32) | (uint32_t)(0xffffffffu - (uint32_t)hyp);
+                best = key > best ? key : best;
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
