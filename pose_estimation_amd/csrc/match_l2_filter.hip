@@ -527,8 +527,8 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
 // 2: 420, benchmarks/dbg/rr_time.py).  (1) Every lane reads its list entries of all segments at once and
 // the query's final bound (second-largest listed sA - 2e) is formed by shuffles; (2) the surviving entries of all sixteen
 // queries (2-3 each) are compacted into a wave queue in LDS; (3) lane i runs the exact fma chain of queued row i, reading
-// the train row and its query's row straight from global memory (a lane walks its 512-byte row front to back, 8 chunks =
-// one cache line in flight per batch; the lanes of one query read the same query addresses); (4) the lanes of a
+// the train row straight from global memory (a lane walks its 512-byte row front to back, 8 chunks = one cache line in
+// flight per batch) and its query's row from a swizzled LDS copy made once per wave; (4) the lanes of a
 // query fold the results of the pass they find under their query's number and merge at the end.
 // The chain is a dependent sequence of 128 fmas per row whatever the layout, so what counts is how many rows one pass of
 // the wave's instructions serves: with the rows staged through LDS (the previous version: 8 rows per pass, 4 KB of LDS per
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
 
     // (1) list entries of this lane (entries sl, sl + kRL, ... of every segment) and the final bound.  The counts and first
     // cache lines of the first two segments (all there are unless the train rows are split) are loaded in one go and kept
-    // in registers for (3).
+    // in registers for (2).
     bool overflow = false;
     float p1 = -INFINITY, p2 = -INFINITY;
     constexpr int kE = 16 / kRL;                           // entries per lane in the first cache line of a segment
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     int max_slots = (live && !overflow && !decided) ? slots : 0;
     for (int w = 32; w > 0; w >>= 1) max_slots = max(max_slots, __shfl_xor(max_slots, w));
     wave_sync();
-    // one candidate row per lane (or -1) -> wave queue; flushes whole chunks when the queue reaches kRC entries
+    // one candidate row per lane (or -1) -> wave queue; the queue is flushed early only when it reaches kRQueue entries
     auto enqueue = [&](int j) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(j >= 0);
         if (m == 0ull) return;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     };
     if (max_slots > 0) {
 #pragma unroll
-        for (int slot = 0; slot < 2; ++slot) {             // the first two segments: out of the registers of (2)
+        for (int slot = 0; slot < 2; ++slot) {             // the first two segments: out of the registers of (1)
             const int c = use ? min(cn[slot], kCapH) : 0;
 #pragma unroll
             for (int k = 0; k < kE; ++k)
