@@ -109,10 +109,11 @@ int ph_match_l2_top2_timed(const float* desc_q, const float* desc_t,
                            void* ws, size_t ws_bytes, void* stream, void* ev_begin, void* ev_end);
 
 /* ph_match_l2_ratio: matching and ratio test in one call (north_star 1: "descriptor matching + ratio test"; no reference
- * counterpart).  idx and keep are, bit for bit, what ph_match_l2_top2(precision = PH_PRECISION_F16_RERANK) followed by
- * ph_ratio_filter_l2(ratio) write — but a query whose best row and whose ratio decision already follow from the candidate
+ * counterpart): the accepted matches.  keep is, bit for bit, what ph_match_l2_top2(precision = PH_PRECISION_F16_RERANK)
+ * followed by ph_ratio_filter_l2(ratio) write; idx is their idx where keep = 1 and PH_NO_INDEX where keep = 0 (a rejected
+ * query reports no match).  A query whose decision (and, if kept, whose best row) already follows from the candidate
  * filter's approximate scores and their proven error band is never re-scored exactly (a planted match wins by far, a
- * non-match fails by far: nine queries of ten); the others take the exact path.  The distances themselves are not returned.
+ * non-match fails by far: 99 queries of 100); the others take the exact path.  The distances are not returned.
  * dim = 128 only; workspace as for ph_match_l2_top2 with that precision; ev_begin / ev_end as in ph_match_l2_top2_timed
  * (NULL = no events). */
 int ph_match_l2_ratio(const float* desc_q, const float* desc_t,

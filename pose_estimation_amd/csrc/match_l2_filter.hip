@@ -551,14 +551,15 @@ struct RerankLds {
     float4 qrow[kRQ * 32];             // the wave's query rows: query d's chunk c at d*32 + (c ^ d)
 #endif
 };
-// FUSE = the ratio test in the same kernel (ph_match_l2_ratio): outputs idx and keep = what ph_match_l2_top2 followed by
-// ph_ratio_filter_l2 give, bit for bit, but a query whose answer already follows from the APPROXIMATE scores skips the exact
-// chains altogether.  With a(1) >= a(2) the two largest listed approximate scores (unscaled) and e the filter's error bound,
+// FUSE = the ratio test in the same kernel (ph_match_l2_ratio): keep = what ph_match_l2_top2 followed by ph_ratio_filter_l2
+// give, bit for bit, idx = their idx where keep is set and PH_NO_INDEX where it is not, but a query whose answer already
+// follows from the APPROXIMATE scores skips the exact chains altogether.  With a(1) >= a(2) the two largest listed approximate scores (unscaled) and e the filter's error bound,
 // the exact best and runner-up scores lie in [a(1) - e, a(1) + e] and [a(2) - e, a(2) + e]; if a(1) - a(2) > 2e the best row is
 // the row of a(1), uniquely; and d = max(0, |q|^2 - 2 m) turns the two intervals into intervals of d1sq and d2sq (widened by
 // 2^-20 relative for the float32 roundings of the contract's own fma and product and of this arithmetic).  If these decide
-// d1sq < r2 * d2sq one way or the other the query is done — nine of ten are: a planted match wins by far, a non-match
-// fails by far; the others take the exact path, so the outputs never differ from the two-kernel path.
+// d1sq < r2 * d2sq one way or the other the query is done (a kept one also needs the separated best row) — 99 of 100
+// are: a planted match wins by far, a non-match fails by far; the others take the exact path, so the outputs never differ
+// from the two-kernel path.
 template <bool FUSE>
 __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
@@ -661,7 +662,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     overflow |= sc.bad;                                    // wave-uniform per pair: the lists of such a pair are not used
     bool decided = false, decided_keep = false;            // FUSE: the query's idx and keep follow from the approximate scores
     const bool has1 = p1 > -INFINITY, has2 = p2 > -INFINITY;                    // no arithmetic on infinities below
-    if (FUSE && live && !overflow && has1 && (!has2 || (p1 - p2) > band)) {     // the row of a(1) is the exact best
+    if (FUSE && live && !overflow && has1) {
         if (!has2) {                                       // one valid train row: no runner-up, the ratio test fails
             decided = true;
         } else {
@@ -673,7 +674,9 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
             const float d1_hi = fmaxf(0.0f, c1 + w1), d1_lo = fmaxf(0.0f, c1 - w1);
             const float d2_hi = fmaxf(0.0f, c2 + w2), d2_lo = fmaxf(0.0f, c2 - w2);
             const float rhs_lo = r2 * d2_lo * (1.0f - 9.5367431640625e-7f), rhs_hi = r2 * d2_hi * (1.0f + 9.5367431640625e-7f);
-            if (d1_hi < rhs_lo) { decided = true; decided_keep = true; }
+            // kept for sure needs the best ROW too (a(1) - a(2) > 2e: the row of a(1) is the exact best, uniquely);
+            // dropped for sure needs no row: a rejected query reports no match
+            if (d1_hi < rhs_lo && (p1 - p2) > band) { decided = true; decided_keep = true; }
             else if (d1_lo > rhs_hi) decided = true;
         }
     }
@@ -795,9 +798,12 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         const float d1 = (bi >= 0) ? fmaxf(0.0f, ph_fma(-2.0f, m1, qn)) : INFINITY;
         const float d2 = (m2 > -INFINITY) ? fmaxf(0.0f, ph_fma(-2.0f, m2, qn)) : INFINITY;
         if (FUSE) {
-            if (!live) { idx[o] = PH_NO_INDEX; keep_out[o] = 0; }
-            else if (decided) { idx[o] = j1; keep_out[o] = decided_keep ? 1 : 0; }
-            else { idx[o] = bi; keep_out[o] = (bi >= 0 && d2 < INFINITY && d1 < r2 * d2) ? 1 : 0; }   // ph_ratio_filter_l2's test
+            bool k = false;
+            int32_t ji = PH_NO_INDEX;
+            if (live && decided) { k = decided_keep; ji = j1; }
+            else if (live) { k = bi >= 0 && d2 < INFINITY && d1 < r2 * d2; ji = bi; }       // ph_ratio_filter_l2's test
+            idx[o] = k ? ji : PH_NO_INDEX;                     // a rejected query has no match
+            keep_out[o] = k ? 1 : 0;
         } else {
             if (!live) { idx[o] = PH_NO_INDEX; d1sq[o] = INFINITY; d2sq[o] = INFINITY; return; }
             idx[o] = bi; d1sq[o] = d1; d2sq[o] = d2;

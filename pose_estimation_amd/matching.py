@@ -136,9 +136,9 @@ def ratio_filter_hamming(idx, d1, d2, ratio=0.75):
 def match_l2_ratio(desc_q, desc_t, ratio, view_q=None, view_t=None, n_q=None, n_t=None, norm_q=None, norm_t=None,
                    kernel_events=None):
     """Squared-L2 matching and Lowe's ratio test in one call (``ph_match_l2_ratio``).  Returns (idx int32, keep int32), each
-    ``[B, nq]`` — bit for bit what ``match_l2`` (default precision) followed by ``ratio_filter_l2`` return, without the
-    distances: a query whose best row and ratio decision already follow from the candidate filter's approximate scores is
-    never re-scored exactly.  dim = 128 only."""
+    ``[B, nq]``: keep is bit for bit what ``match_l2`` (default precision) followed by ``ratio_filter_l2`` return, idx their
+    idx where keep is set and -1 elsewhere; no distances.  A query whose decision already follows from the candidate
+    filter's approximate scores is never re-scored exactly.  dim = 128 only."""
     lib = L.load()
     desc_q = L.dev(desc_q, torch.float32, "desc_q")
     desc_t = L.dev(desc_t, torch.float32, "desc_t")

@@ -1,6 +1,6 @@
 """ph_match_l2_ratio (matching + ratio test in one call, exact chains skipped where the approximate scores decide) against
-the two-call path it must equal bit for bit: ph_match_l2_top2 (bit-exact to the oracle, tests/test_gpu_matching.py) followed
-by ph_ratio_filter_l2."""
+the two-call path: ph_match_l2_top2 (bit-exact to the oracle, tests/test_gpu_matching.py) followed by ph_ratio_filter_l2 —
+keep must be equal bit for bit, idx equal where keep is set and -1 where it is not."""
 import os
 
 import numpy as np
@@ -20,7 +20,9 @@ def _both(q, t, ratio, device, **kw):
     idx, d1, d2 = matching.match_l2(q, t, **kw)
     keep = matching.ratio_filter_l2(idx, d1, d2, ratio)
     fi, fk = matching.match_l2_ratio(q, t, ratio, **kw)
-    return idx.cpu().numpy(), keep.cpu().numpy(), fi.cpu().numpy(), fk.cpu().numpy(), d1.cpu().numpy(), d2.cpu().numpy()
+    idx, keep = idx.cpu().numpy(), keep.cpu().numpy()
+    idx = np.where(keep == 1, idx, -1)                      # the fused call reports no match for a rejected query
+    return idx, keep, fi.cpu().numpy(), fk.cpu().numpy(), d1.cpu().numpy(), d2.cpu().numpy()
 
 
 @pytest.mark.parametrize("ratio", [0.5, 0.75, 0.9, 1.0])
@@ -105,4 +107,4 @@ def test_fused_empty_and_single_train_row(device):
     assert (idx.cpu().numpy() == -1).all() and (keep.cpu().numpy() == 0).all()
     t = q[:, :1].copy()
     idx, keep = matching.match_l2_ratio(_t(q, device), _t(t, device), 0.75)
-    assert (idx.cpu().numpy() == 0).all() and (keep.cpu().numpy() == 0).all()   # no second neighbour: rejected
+    assert (idx.cpu().numpy() == -1).all() and (keep.cpu().numpy() == 0).all()  # no second neighbour: rejected, no match
