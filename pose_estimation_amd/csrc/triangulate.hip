@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int kSweeps = 4;   // measured against a float64 SVD on the CPU, baselines 0.5 / 0.05 / 0.005 m: 3, 4, 5 and 6 sweeps give the same error to 3 digits
+constexpr int kSweeps = 3;   // measured against a float64 SVD on the CPU, baselines 0.5 / 0.05 / 0.005 m: 3, 4, 5 and 6 sweeps give the same error to 3 digits (4 until late in round 2: a quarter of the kernel for nothing)
 
 __device__ __forceinline__ void rotate_cols(float (&A)[4][4], float (&V)[4][4], int p, int q) {
     float alpha = 0.f, beta = 0.f, gamma = 0.f;
