@@ -318,12 +318,25 @@ PH_HD inline cplx aberth_start10(const double (&c)[11], int n, int k) {
     return {rad * cos(a), rad * sin(a)};
 }
 PH_HD inline cplx aberth_step10(const double (&c)[11], cplx zk, cplx sum) {
-    cplx p = {c[10], 0.0}, dp = {0.0, 0.0};
+    // p(z) and p'(z) of a REAL polynomial at a complex point by synthetic division with the real quadratic
+    // x^2 - r x + s (r = 2 Re z, s = |z|^2) that has z as a root: two real fmas per coefficient instead of a complex
+    // Horner step (eleven).  p(x) = (x^2 - r x + s) q(x) + b1 x + (b0 - r b1)  =>  p(z) = b1 z + b0 - r b1, and
+    // p'(z) = (2z - r) q(z) + b1 with q evaluated the same way (2z - r = 2i Im z).
+    const double r = 2.0 * zk.re, sq = zk.re * zk.re + zk.im * zk.im;
+    double b[11];
+    b[10] = c[10];
+    b[9] = c[9] + r * b[10];
 #pragma unroll
-    for (int j = 9; j >= 0; --j) {
-        dp = cmul(dp, zk); dp.re += p.re; dp.im += p.im;
-        p = cmul(p, zk); p.re += c[j];
-    }
+    for (int k = 8; k >= 0; --k) b[k] = c[k] + r * b[k + 1] - sq * b[k + 2];
+    // q(x) = sum_{k=0..8} b[k+2] x^k
+    double d1 = b[10], d0 = b[9] + r * d1;                 // d_8, d_7 of the second division
+#pragma unroll
+    for (int k = 6; k >= 0; --k) { const double t = b[k + 2] + r * d0 - sq * d1; d1 = d0; d0 = t; }
+    // after the loop: d0 = d_0, d1 = d_1  =>  q(z) = d1 z + d0 - r d1
+    const cplx p = {b[1] * zk.re + b[0] - r * b[1], b[1] * zk.im};
+    const cplx qz = {d1 * zk.re + d0 - r * d1, d1 * zk.im};
+    const double tz = 2.0 * zk.im;                         // (2z - r) = i * tz
+    const cplx dp = {b[1] - tz * qz.im, tz * qz.re};
     if (p.re == 0.0 && p.im == 0.0) return {0.0, 0.0};
     const cplx nw = cdiv(p, dp);                          // Newton step
     const cplx den = {1.0 - (nw.re * sum.re - nw.im * sum.im), -(nw.re * sum.im + nw.im * sum.re)};
