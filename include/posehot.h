@@ -348,6 +348,14 @@ int ph_refine_pose_lm_soa(const float* X, const float* Y, const float* Z, const 
                           const double* K4, const double* dist5, int max_iters,
                           double* pose, double* rms, int32_t* iters, void* stream);
 
+/* Initial pose of coplanar (z = 0) point sets from the plane-to-image homography: the first half of
+ * cv2.solvePnP(..., SOLVEPNP_ITERATIVE) on board points (main.py:101-104 == validate_pose.py:93-96; the algorithm inside OpenCV,
+ * restated: normalised DLT on undistorted points, decomposition, nearest rotation) — what ph_refine_pose_lm starts from.
+ * obj [B][N][3] f32 (z ignored), img [B][N][2] f32 pixels, n_valid [B] or NULL; pose [B][6] f64 (rvec, tvec);
+ * ok [B] (may be NULL): 0 for fewer than 4 points or a non-finite result (pose then NaN), else 1. */
+int ph_initial_board_pose(const float* obj, const float* img, const int32_t* n_valid, int B, int N,
+                          const double* K4, const double* dist5, double* pose, int32_t* ok, void* stream);
+
 /* (rvec, tvec) [B][6] f64 of hypothesis sel[b] (NULL = 0) of item b's [H][12] f32 block of 3x4 matrices
  * K [R|t] (K4 given) or [R|t] (K4 NULL): the initial pose ph_refine_pose_lm* starts from after ph_select_best.
  * No reference counterpart (glue between north_star's RANSAC and main.py:101-104's refinement). */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ph_refine_pose_lm": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ph_refine_pose_lm_soa": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ph_pose_from_projection": (_i, [_p, _p, _i, _i, _p, _p, _p]),
+    "ph_initial_board_pose": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "ph_camera_from_pose": (_i, [_p, _i, _p, _p]),
     "ph_undistort_points": (_i, [_p, _p, _p, _i64, _i, _p, _p]),
 }

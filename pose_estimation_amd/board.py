@@ -346,29 +346,64 @@ def initial_board_pose(obj_points, img_points, camera_matrix, dist_coeffs):
     return pose if np.all(np.isfinite(pose)) else None
 
 
-def solve_pnp_iterative_batched(items, camera_matrix, dist_coeffs, max_iters=30):
-    """cv2.solvePnP(..., SOLVEPNP_ITERATIVE) for many coplanar point sets in one launch.
+def initial_board_pose_batched(obj, img, n_valid=None, camera_matrix=CAMERA_MATRIX, dist_coeffs=DIST_COEFFS):
+    """Homography-based initial poses of many coplanar point sets on the device (``ph_initial_board_pose``).
+
+    obj [B,N,3] f32, img [B,N,2] f32 on the GPU.  Returns (pose [B,6] f64, ok [B] int32)."""
+    lib = L.load()
+    obj, img = L.dev(obj, torch.float32, "obj"), L.dev(img, torch.float32, "img")
+    B, N = obj.shape[0], obj.shape[1]
+    K4, d5 = _cam_tensors(camera_matrix, dist_coeffs, obj.device)
+    n_valid = L.opt_i32(n_valid, B, "n_valid")
+    pose = torch.empty((B, 6), dtype=torch.float64, device=obj.device)
+    ok = torch.empty((B,), dtype=torch.int32, device=obj.device)
+    L.check(lib.ph_initial_board_pose(L.ptr(obj), L.ptr(img), L.ptr(n_valid), B, N, L.ptr(K4), L.ptr(d5), L.ptr(pose),
+                                      L.ptr(ok), L.stream_ptr()), "ph_initial_board_pose")
+    return pose, ok
+
+
+def solve_pnp_iterative_batched(items, camera_matrix, dist_coeffs, max_iters=30, init="device"):
+    """cv2.solvePnP(..., SOLVEPNP_ITERATIVE) for many coplanar point sets in two launches.
 
     items: list of (obj_points, img_points).  Returns a list of (success, rvec (3,1), tvec (3,1)):
-    homography initial pose per item on the host (a 9x9 SVD each), then ONE batched
-    Levenberg-Marquardt launch on the GPU (ph_refine_pose_lm)."""
-    inits = [initial_board_pose(o, i, camera_matrix, dist_coeffs) for o, i in items]
-    good = [k for k, p in enumerate(inits) if p is not None]
+    homography initial pose (init="device": one ``ph_initial_board_pose`` launch for all items; "host": a NumPy SVD per
+    item, the twin the device kernel is tested against), then ONE batched Levenberg-Marquardt launch on the GPU
+    (``ph_refine_pose_lm``)."""
+    if init not in ("device", "host"):
+        raise ValueError("init must be 'device' or 'host'")
     out = [(False, None, None)] * len(items)
+    shaped = []
+    for o, i in items:
+        o = np.asarray(o, np.float32).reshape(-1, 3); i = np.asarray(i, np.float32).reshape(-1, 2)
+        shaped.append((o, i) if len(o) >= 4 and len(o) == len(i) else None)
+    if init == "host":
+        inits = [None if s is None else initial_board_pose(s[0], s[1], camera_matrix, dist_coeffs) for s in shaped]
+        good = [k for k, p in enumerate(inits) if p is not None]
+    else:
+        good = [k for k, s in enumerate(shaped) if s is not None]
     if not good:
         return out
     dev = _device()
-    N = max(len(np.asarray(items[k][0]).reshape(-1, 3)) for k in good)
+    N = max(len(shaped[k][0]) for k in good)
     obj = np.zeros((len(good), N, 3), np.float32); img = np.zeros((len(good), N, 2), np.float32)
     nv = np.zeros(len(good), np.int32); pose = np.zeros((len(good), 6), np.float64)
     for r, k in enumerate(good):
-        o = np.asarray(items[k][0], np.float32).reshape(-1, 3); i = np.asarray(items[k][1], np.float32).reshape(-1, 2)
-        nv[r] = len(o); obj[r, :len(o)] = o; img[r, :len(o)] = i; pose[r] = inits[k]
+        o, i = shaped[k]
+        nv[r] = len(o); obj[r, :len(o)] = o; img[r, :len(o)] = i
+        if init == "host":
+            pose[r] = inits[k]
     t = lambda a: torch.from_numpy(a).to(dev)
-    refined, _, _ = refine_pose_lm_batched(t(obj), t(img), t(pose), t(nv), camera_matrix, dist_coeffs, max_iters)
+    obj_d, img_d, nv_d = t(obj), t(img), t(nv)
+    if init == "device":
+        pose_d, ok0 = initial_board_pose_batched(obj_d, img_d, nv_d, camera_matrix, dist_coeffs)
+        pose_d = torch.where(ok0[:, None] != 0, pose_d, torch.zeros_like(pose_d))     # a failed start stays out of the LM's way
+        ok0 = ok0.cpu().numpy()
+    else:
+        pose_d, ok0 = t(pose), np.ones(len(good), np.int32)
+    refined, _, _ = refine_pose_lm_batched(obj_d, img_d, pose_d, nv_d, camera_matrix, dist_coeffs, max_iters)
     refined = refined.cpu().numpy()
     for r, k in enumerate(good):
-        ok = bool(np.all(np.isfinite(refined[r])))
+        ok = bool(ok0[r]) and bool(np.all(np.isfinite(refined[r])))
         out[k] = (ok, refined[r, :3].reshape(3, 1).copy(), refined[r, 3:].reshape(3, 1).copy()) if ok else (False, None, None)
     return out
 

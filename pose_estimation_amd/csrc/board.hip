@@ -485,6 +485,166 @@ __global__ __launch_bounds__(64) void pose_from_projection_kernel(const float* _
 
 // get_camera_position_and_orientation (main.py:112-143), batched: per pose 22 doubles =
 // position (3) | forward (3) | up (3) | R_cam_to_world row-major (9) | quaternion w,x,y,z (4).
+// ---------------------------------------------------------------------------------------------
+// Initial pose of a coplanar (z = 0) point set from the plane-to-image homography — the first half of
+// cv2.solvePnP(SOLVEPNP_ITERATIVE) on board points (main.py:101-104), batched: one 256-thread block per image.
+// Normalised DLT: image points undistorted (20 fixed-point steps), both point sets centred and scaled to mean distance
+// sqrt(2); the 2n x 9 system enters as its 9 x 9 normal matrix A'A (45 block-reduced sums; the normalisation keeps its
+// condition number near 1e2..1e4, and the Levenberg-Marquardt stage that follows removes what the squaring costs), whose
+// eigenvector of the smallest eigenvalue (cyclic Jacobi, one thread, matrices in LDS) is the homography; then
+// H = Ti^-1 Hn To, scale 2 / (|h1| + |h2|), sign from the board lying in front of the camera, and the nearest rotation to
+// [r1 r2 r1 x r2] by Newton's polar iteration X <- (X + X^-T) / 2 (the U V' of the SVD the host twin takes).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void initial_pose_kernel(const float* __restrict__ obj, const float* __restrict__ img,
+                                                          const int32_t* __restrict__ n_valid, int N,
+                                                          const double* __restrict__ K4, const double* __restrict__ d5,
+                                                          double* __restrict__ pose, int32_t* __restrict__ ok_out) {
+    __shared__ double red[4][45];
+    __shared__ double M[81], V[81];
+    __shared__ double sh[8];                               // mo.x mo.y mi.x mi.y so si
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    const Cam cam = load_cam(K4, d5);
+    double* P = pose + (size_t)b * 6;
+    if (nv < 4) {                                          // uniform
+        if (tid == 0) { for (int k = 0; k < 6; ++k) P[k] = NAN; if (ok_out) ok_out[b] = 0; }
+        return;
+    }
+    auto point = [&](int i, double& X, double& Y, double& x, double& y) {
+        const float* o = obj + ((size_t)b * N + i) * 3;
+        const float* m = img + ((size_t)b * N + i) * 2;
+        X = o[0]; Y = o[1];
+        const double x0 = ((double)m[0] - cam.cx) / cam.fx, y0 = ((double)m[1] - cam.cy) / cam.fy;
+        x = x0; y = y0;
+        for (int it = 0; it < 20; ++it) {
+            const double r2 = x * x + y * y;
+            const double icd = 1.0 / (1 + ((cam.k3 * r2 + cam.k2) * r2 + cam.k1) * r2);
+            const double dx = 2 * cam.p1 * x * y + cam.p2 * (r2 + 2 * x * x);
+            const double dy = cam.p1 * (r2 + 2 * y * y) + 2 * cam.p2 * x * y;
+            x = (x0 - dx) * icd; y = (y0 - dy) * icd;
+        }
+    };
+    auto block_sum = [&](double (&a)[45], int n) {         // sums of a[0..n) over the block -> red[0][0..n)
+#pragma unroll
+        for (int k = 0; k < 45; ++k) if (k < n) a[k] = wave_sum(a[k]);
+        __syncthreads();                                   // red is free again
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 45; ++k) if (k < n) red[wave][k] = a[k];
+        __syncthreads();
+        if (tid < n) red[0][tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        __syncthreads();
+    };
+    double a[45];
+    // pass 1: centroids
+#pragma unroll
+    for (int k = 0; k < 45; ++k) a[k] = 0.0;
+    for (int i = tid; i < nv; i += 256) { double X, Y, x, y; point(i, X, Y, x, y); a[0] += X; a[1] += Y; a[2] += x; a[3] += y; }
+    block_sum(a, 4);
+    if (tid < 4) sh[tid] = red[0][tid] / nv;
+    __syncthreads();
+    const double mox = sh[0], moy = sh[1], mix = sh[2], miy = sh[3];
+    // pass 2: mean distances to the centroids
+#pragma unroll
+    for (int k = 0; k < 45; ++k) a[k] = 0.0;
+    for (int i = tid; i < nv; i += 256) {
+        double X, Y, x, y; point(i, X, Y, x, y);
+        a[0] += sqrt((X - mox) * (X - mox) + (Y - moy) * (Y - moy));
+        a[1] += sqrt((x - mix) * (x - mix) + (y - miy) * (y - miy));
+    }
+    block_sum(a, 2);
+    if (tid < 2) sh[4 + tid] = 1.4142135623730951 / fmax(red[0][tid] / nv, 1e-12);
+    __syncthreads();
+    const double so = sh[4], si = sh[5];
+    // pass 3: A'A of the rows [Pn 1 0 0 0 -x Pn -x] and [0 0 0 Pn 1 -y Pn -y]
+#pragma unroll
+    for (int k = 0; k < 45; ++k) a[k] = 0.0;
+    for (int i = tid; i < nv; i += 256) {
+        double X, Y, x, y; point(i, X, Y, x, y);
+        const double px = (X - mox) * so, py = (Y - moy) * so, xn = (x - mix) * si, yn = (y - miy) * si;
+        const double ra[9] = {px, py, 1.0, 0.0, 0.0, 0.0, -xn * px, -xn * py, -xn};
+        const double rb[9] = {0.0, 0.0, 0.0, px, py, 1.0, -yn * px, -yn * py, -yn};
+        int q = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r)
+#pragma unroll
+            for (int c = r; c < 9; ++c) a[q++] += ra[r] * ra[c] + rb[r] * rb[c];
+    }
+    block_sum(a, 45);
+    if (tid != 0) return;
+    {
+        int q = 0;
+        for (int r = 0; r < 9; ++r)
+            for (int c = r; c < 9; ++c) { M[9 * r + c] = red[0][q]; M[9 * c + r] = red[0][q]; ++q; }
+        for (int k = 0; k < 81; ++k) V[k] = (k % 10 == 0) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 12; ++sweep) {             // cyclic Jacobi on the symmetric 9 x 9
+        double off = 0.0;
+        for (int r = 0; r < 9; ++r) for (int c = r + 1; c < 9; ++c) off += M[9 * r + c] * M[9 * r + c];
+        if (off < 1e-40) break;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = M[9 * p + q];
+                if (apq == 0.0) continue;
+                const double theta = (M[9 * q + q] - M[9 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 9; ++k) {              // columns p, q
+                    const double mkp = M[9 * k + p], mkq = M[9 * k + q];
+                    M[9 * k + p] = c * mkp - s * mkq; M[9 * k + q] = s * mkp + c * mkq;
+                }
+                for (int k = 0; k < 9; ++k) {              // rows p, q
+                    const double mpk = M[9 * p + k], mqk = M[9 * q + k];
+                    M[9 * p + k] = c * mpk - s * mqk; M[9 * q + k] = s * mpk + c * mqk;
+                }
+                for (int k = 0; k < 9; ++k) {
+                    const double vkp = V[9 * k + p], vkq = V[9 * k + q];
+                    V[9 * k + p] = c * vkp - s * vkq; V[9 * k + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int kmin = 0;
+    for (int k = 1; k < 9; ++k) if (M[10 * k] < M[10 * kmin]) kmin = k;
+    double Hn[9];
+    for (int k = 0; k < 9; ++k) Hn[k] = V[9 * k + kmin];
+    // H = Ti^-1 Hn To,  Ti^-1 = [1/si 0 mi.x; 0 1/si mi.y; 0 0 1],  To = [so 0 -so mo.x; 0 so -so mo.y; 0 0 1]
+    double G[9], H[9];
+    const double isi = 1.0 / si;
+    for (int c = 0; c < 3; ++c) {
+        G[c] = isi * Hn[c] + mix * Hn[6 + c];
+        G[3 + c] = isi * Hn[3 + c] + miy * Hn[6 + c];
+        G[6 + c] = Hn[6 + c];
+    }
+    for (int r = 0; r < 3; ++r) {
+        H[3 * r] = G[3 * r] * so; H[3 * r + 1] = G[3 * r + 1] * so;
+        H[3 * r + 2] = -so * mox * G[3 * r] - so * moy * G[3 * r + 1] + G[3 * r + 2];
+    }
+    const double n1 = sqrt(H[0] * H[0] + H[3] * H[3] + H[6] * H[6]), n2 = sqrt(H[1] * H[1] + H[4] * H[4] + H[7] * H[7]);
+    double lam = 2.0 / (n1 + n2);
+    if (H[8] * lam < 0.0) lam = -lam;                      // board in front of the camera
+    const double r1[3] = {lam * H[0], lam * H[3], lam * H[6]}, r2[3] = {lam * H[1], lam * H[4], lam * H[7]};
+    const double t[3] = {lam * H[2], lam * H[5], lam * H[8]};
+    const double r3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+    double X[9] = {r1[0], r2[0], r3[0], r1[1], r2[1], r3[1], r1[2], r2[2], r3[2]};
+    for (int it = 0; it < 30; ++it) {                      // polar factor: X <- (X + X^-T) / 2
+        const double c00 = X[4] * X[8] - X[5] * X[7], c01 = X[5] * X[6] - X[3] * X[8], c02 = X[3] * X[7] - X[4] * X[6];
+        const double c10 = X[2] * X[7] - X[1] * X[8], c11 = X[0] * X[8] - X[2] * X[6], c12 = X[1] * X[6] - X[0] * X[7];
+        const double c20 = X[1] * X[5] - X[2] * X[4], c21 = X[2] * X[3] - X[0] * X[5], c22 = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * c00 + X[1] * c01 + X[2] * c02;
+        const double id = 1.0 / det;
+        const double Y[9] = {c00 * id, c01 * id, c02 * id, c10 * id, c11 * id, c12 * id, c20 * id, c21 * id, c22 * id};   // X^-T
+        double change = 0.0;
+        for (int k = 0; k < 9; ++k) { const double nx = 0.5 * (X[k] + Y[k]); change += fabs(nx - X[k]); X[k] = nx; }
+        if (change < 1e-15) break;
+    }
+    const double R[9] = {X[0], X[1], X[2], X[3], X[4], X[5], X[6], X[7], X[8]};
+    double w[3];
+    log_so3(R, w);
+    bool fin = true;
+    for (int k = 0; k < 3; ++k) { P[k] = w[k]; P[3 + k] = t[k]; fin = fin && (w[k] - w[k] == 0.0) && (t[k] - t[k] == 0.0); }
+    if (ok_out) ok_out[b] = fin ? 1 : 0;
+}
+
 // Quaternion: the algorithm of scipy Rotation.from_matrix(...).as_quat() for a proper rotation
 // (largest of the three diagonal entries and the trace picks the branch; no sign canonicalisation),
 // re-ordered to [w, x, y, z] as main.py:138-141 does.
@@ -599,6 +759,16 @@ extern "C" int ph_pose_from_projection(const float* P, const int32_t* sel, int H
     if (!P || !pose) return PH_ERR_INVALID_ARG;
     hipLaunchKernelGGL(pose_from_projection_kernel, dim3(ph_ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, P, sel, H, B,
                        K4, pose);
+    return ph_launch_status();
+}
+
+extern "C" int ph_initial_board_pose(const float* obj, const float* img, const int32_t* n_valid, int B, int N,
+                                     const double* K4, const double* dist5, double* pose, int32_t* ok, void* stream) {
+    if (B < 0 || N < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0) return PH_OK;
+    if (!pose || !K4 || !dist5 || (N > 0 && (!obj || !img))) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(initial_pose_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, obj, img, n_valid, N, K4, dist5, pose, ok);
     return ph_launch_status();
 }
 

@@ -68,13 +68,50 @@ def test_undistort_inverts_distortion(device):
 
 
 def test_estimate_board_pose_recovers_synthetic_pose(device):
-    """main.py:86-109 through the reference-named function: homography init (host) + device LM."""
+    """main.py:86-109 through the reference-named function: homography init + LM, both on the device."""
     _, b = board.create_aruco_board()
     for v in synthetic.board_views(3, seed=9, noise_px=0.3):
         rvec, tvec, n = board.estimate_board_pose(v["corners"], v["ids"], b, board.CAMERA_MATRIX, board.DIST_COEFFS)
         assert n == 77 and rvec.shape == (3, 1) and tvec.shape == (3, 1) and rvec.dtype == np.float64
         assert geometry.rotation_angle_deg(board.rodrigues(rvec), v["R"]) < 0.05
         assert np.linalg.norm(tvec.flatten() - v["t"]) < 5e-4
+
+
+def test_initial_board_pose_device_equals_host_twin(device):
+    """ph_initial_board_pose (normal matrix + Jacobi eigenvector + Newton polar factor) against board.initial_board_pose
+    (NumPy SVDs) on full and partial boards with noise; then both starts must lead the LM to the same pose."""
+    _, b = board.create_aruco_board()
+    vs = synthetic.board_views(8, seed=21, noise_px=0.5, drop=0.5) + synthetic.board_views(4, seed=22, noise_px=0.0)
+    items = [b.matchImagePoints(v["corners"], v["ids"]) for v in vs]
+    N = max(len(o) for o, _ in items)
+    obj = np.zeros((len(items), N, 3), np.float32); img = np.zeros((len(items), N, 2), np.float32); nv = np.zeros(len(items), np.int32)
+    for r, (o, i) in enumerate(items):
+        o = np.asarray(o, np.float32).reshape(-1, 3); i = np.asarray(i, np.float32).reshape(-1, 2)
+        nv[r] = len(o); obj[r, :len(o)] = o; img[r, :len(o)] = i
+    pose, ok = board.initial_board_pose_batched(_t(obj, device), _t(img, device), _t(nv, device))
+    pose, ok = pose.cpu().numpy(), ok.cpu().numpy()
+    assert ok.all()
+    for r, (o, i) in enumerate(items):
+        ref = board.initial_board_pose(o, i, board.CAMERA_MATRIX, board.DIST_COEFFS)
+        assert geometry.rotation_angle_deg(board.rodrigues(pose[r, :3]), board.rodrigues(ref[:3])) < 1e-6
+        assert np.abs(pose[r, 3:] - ref[3:]).max() < 1e-8
+    dev_out = board.solve_pnp_iterative_batched(items, board.CAMERA_MATRIX, board.DIST_COEFFS, init="device")
+    host_out = board.solve_pnp_iterative_batched(items, board.CAMERA_MATRIX, board.DIST_COEFFS, init="host")
+    for (s1, r1, t1), (s2, r2, t2) in zip(dev_out, host_out):
+        assert s1 and s2 and np.abs(r1 - r2).max() < 1e-9 and np.abs(t1 - t2).max() < 1e-9
+
+
+def test_initial_board_pose_guards(device):
+    """Fewer than four points: ok = 0 and a NaN pose; solve_pnp_iterative_batched reports failure for that item only."""
+    _, b = board.create_aruco_board()
+    v = synthetic.board_views(1, seed=5)[0]
+    o, i = b.matchImagePoints(v["corners"], v["ids"])
+    o = np.asarray(o, np.float32).reshape(-1, 3); i = np.asarray(i, np.float32).reshape(-1, 2)
+    obj = np.stack([o, o]); img = np.stack([i, i])
+    pose, ok = board.initial_board_pose_batched(_t(obj, device), _t(img, device), _t(np.array([3, len(o)], np.int32), device))
+    assert ok.cpu().numpy().tolist() == [0, 1] and np.isnan(pose.cpu().numpy()[0]).all()
+    out = board.solve_pnp_iterative_batched([(o[:3], i[:3]), (o, i)], board.CAMERA_MATRIX, board.DIST_COEFFS)
+    assert out[0] == (False, None, None) and out[1][0]
 
 
 def test_estimate_board_poses_batched_equals_per_image(device):
