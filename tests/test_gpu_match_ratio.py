@@ -108,3 +108,21 @@ def test_fused_empty_and_single_train_row(device):
     t = q[:, :1].copy()
     idx, keep = matching.match_l2_ratio(_t(q, device), _t(t, device), 0.75)
     assert (idx.cpu().numpy() == -1).all() and (keep.cpu().numpy() == 0).all()  # no second neighbour: rejected, no match
+
+
+def test_fused_nan_rows_nothing_faults_and_clean_queries_agree(device):
+    """posehot.h: descriptors must be finite.  With a NaN train row and a NaN query the launch still completes, and the
+    queries whose clean top-2 did not involve the NaN row get the keep / idx of the clean two-call path."""
+    rng = np.random.default_rng(5)
+    q = synthetic.sift_like(rng, 700, 128); t = synthetic.sift_like(rng, 900, 128)
+    idx0, keep0, _, _, _, _ = _both(_t(q[None], device), _t(t[None], device), 0.8, device)
+    j0, i0 = 123, 45
+    t2, q2 = t.copy(), q.copy()
+    t2[j0, 17] = np.nan; q2[i0, 3] = np.nan
+    fi, fk = (x.cpu().numpy()[0] for x in matching.match_l2_ratio(_t(q2[None], device), _t(t2[None], device), 0.8))
+    d = ((q[:, None, :].astype(np.float64) - t[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    order = np.argsort(d, axis=1)
+    same = (np.arange(700) != i0) & (order[:, 0] != j0) & (order[:, 1] != j0)
+    assert same.sum() > 600
+    assert np.array_equal(fk[same], keep0[0][same]) and np.array_equal(fi[same], idx0[0][same])
+    assert not (fi == j0).any()
