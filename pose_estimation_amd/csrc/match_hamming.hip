@@ -22,6 +22,9 @@
 
 #include "common.hpp"
 
+#ifndef PH_HAM_ABLATE
+#define PH_HAM_ABLATE 0
+#endif
 namespace {
 
 constexpr int kIdxBits = 22;                      // train rows per view < 2^22
@@ -48,7 +51,8 @@ constexpr int kMR = 32;                           // train rows per MFMA tile
 // a lane does not matter as long as both operands are expanded by the same function (they are).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr float kNoScoreF = -1.0e9f;              // exactly representable, below every real score (>= -256)
+constexpr float kNoScoreF = -1.0e9f;              // exactly representable, below every real score (>= -256); its own floor
+constexpr float kTopFrac = 15.0f / 16.0f;         // the largest row fraction of a key: key > score + kTopFrac <=> a larger score
 
 // 8 bits -> 8 nibbles, bit i at bit 4i
 __device__ __forceinline__ uint32_t spread8(uint32_t x) {
@@ -149,31 +153,36 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     const int t_begin = split * rows_per_split;          // a multiple of kHSR
     const int t_end = min(ntv, t_begin + rows_per_split);
 
+    // When some lane's score beats the entry bound, the scan's 16 scores are turned into keys that carry their row:
+    // key = q.t + (15 - r) / 16 for accumulator register r — q.t is an even integer, the fraction orders equal scores of ONE
+    // scan by row (registers are in increasing row order) and floor() gives the score back.  Keeping a scan's best two keys
+    // is then two instructions per row (max, med3) with no index bookkeeping; the running best of the lane remembers its
+    // tile.  Across scans the comparison is on scores alone (strict '>': the earlier tile keeps a tie).
     auto scan = [&](const f32x16& acc, int ct, int t0) {
         float m4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) m4[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
-        const float bnd = bound[ct];
-        if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])) > bnd) == 0ull) return;
-        const int jb = t0 + 4 * h;
+        if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])) > bound[ct]) == 0ull) return;
+#if PH_HAM_ABLATE & 1
+        if (t0 >= 0) { m1[ct] = fmaxf(m1[ct], m4[0]); return; }     // timing only: no top-2 upkeep
+#endif
+        const float ka = acc[0] + kTopFrac, kb = acc[1] + 14.0f / 16.0f;
+        float k1 = fmaxf(ka, kb), k2 = fminf(ka, kb);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {            // groups and registers in increasing row order: strict '>' keeps the lowest index
-            if (__builtin_amdgcn_ballot_w64(m4[g] > bnd) == 0ull) continue;     // nobody's top-2 changes in this group
-#pragma unroll
-            for (int r = 4 * g; r < 4 * g + 4; ++r) {
-                const float v = acc[r];
-                const bool gt = v > m1[ct];
-                m2[ct] = fmaxf(fminf(m1[ct], v), m2[ct]);
-                m1[ct] = gt ? v : m1[ct];
-                bi[ct] = gt ? jb + (r & 3) + 8 * (r >> 2) : bi[ct];
-            }
+        for (int r = 2; r < 16; ++r) {
+            const float k = acc[r] + (float)(15 - r) * (1.0f / 16.0f);
+            k2 = __builtin_amdgcn_fmed3f(k1, k2, k); k1 = fmaxf(k1, k);
         }
+        const bool gt = k1 > floorf(m1[ct]) + kTopFrac;            // a strictly better score
+        m2[ct] = fmaxf(fmaxf(fminf(m1[ct], k1), k2), m2[ct]);      // only the score of the runner-up is ever used
+        m1[ct] = gt ? k1 : m1[ct];
+        bi[ct] = gt ? t0 : bi[ct];
         // The other lane half scans the other rows of the same query.  A row can only enter the query's top-2 (ties:
-        // lowest index for the best, distance only for the runner-up) if it beats the second-largest score of BOTH
+        // lowest index for the best, distance only for the runner-up) if its score beats the second-largest score of BOTH
         // halves' top-2 together, all from earlier rows — the tighter entry test, refreshed after every scan.
         float l1, h1, l2, h2;
         both_halves(m1[ct], l1, h1); both_halves(m2[ct], l2, h2);
-        bound[ct] = fmaxf(fminf(l1, h1), fmaxf(l2, h2));
+        bound[ct] = floorf(fmaxf(fminf(l1, h1), fmaxf(l2, h2)));
     };
 
     if (t_begin < t_end) {
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
 #pragma unroll
                 for (int ct = 0; ct < QT; ++ct)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[sub][ct][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc[sub][ct][r] = 0.0f;      // the zero C operand is free; a register C is not (9 %)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const uint4 a4 = *(const uint4*)(sm + (aoff[s] + base));
@@ -249,13 +258,17 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
 
 #pragma unroll
     for (int ct = 0; ct < QT; ++ct) {
-        const float om1 = __shfl_xor(m1[ct], 32), om2 = __shfl_xor(m2[ct], 32);
-        const int obi = __shfl_xor(bi[ct], 32);
-        const bool other = (om1 > m1[ct]) || (om1 == m1[ct] && obi >= 0 && (bi[ct] < 0 || obi < bi[ct]));
-        const float lost = other ? m1[ct] : om1;
-        const float nm2 = fmaxf(lost, fmaxf(m2[ct], om2));
-        const float nm1 = other ? om1 : m1[ct];
-        const int nbi = other ? obi : bi[ct];
+        // back to (score, row): the fraction of the best key is its accumulator register
+        const float s1 = floorf(m1[ct]), s2 = floorf(m2[ct]);
+        const int rr = 15 - (int)((m1[ct] - s1) * 16.0f);
+        const int row = bi[ct] >= 0 ? bi[ct] + 4 * h + (rr & 3) + 8 * (rr >> 2) : PH_NO_INDEX;
+        const float om1 = __shfl_xor(s1, 32), om2 = __shfl_xor(s2, 32);
+        const int obi = __shfl_xor(row, 32);
+        const bool other = (om1 > s1) || (om1 == s1 && obi >= 0 && (row < 0 || obi < row));
+        const float lost = other ? s1 : om1;
+        const float nm2 = fmaxf(lost, fmaxf(s2, om2));
+        const float nm1 = other ? om1 : s1;
+        const int nbi = other ? obi : row;
         const int qi = qw0 + ct * 32 + li;
         if (h != 0 || qi >= nq) continue;
         uint32_t k1 = kNoKey, k2 = kNoKey;
