@@ -32,6 +32,9 @@
 
 #include "common.hpp"
 #include "match_l2_filter.hpp"
+#ifndef PH_FILTER_LDS_PAD
+#define PH_FILTER_LDS_PAD 0      // uint4 of unused LDS per block: 464 leaves room for two blocks per CU instead of three (experiments)
+#endif
 #ifndef PH_ABLATE
 #define PH_ABLATE 0
 #endif
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
     static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256 && kSub * kTR <= 256, "staging deal");
-    __shared__ uint4 smem[(kDepth + 1) * kImg];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
+    __shared__ uint4 smem[(kDepth + 1) * kImg + PH_FILTER_LDS_PAD];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
