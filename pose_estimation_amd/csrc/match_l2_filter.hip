@@ -56,7 +56,8 @@ constexpr int kDim = 128;
 constexpr int kCPR = kDim / 8;  // 16-byte fp16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
 constexpr int kCapH = 32;      // list entries per (query, split, lane half)
-constexpr int kBlocksPerCU = 2;
+constexpr int kBlocksPerCU = 2;   // blocks per CU the split count of a SMALL batch aims at (3, the residency, times the same: 8 pairs
+                                  // 6 % faster, 16 pairs 7 % slower)
 constexpr int kDepth = 2;         // staged tiles copied ahead of the one being worked on (3: same time; 4: slower)
 constexpr int kPrimeRows = 512;   // rows of the priming pass (per split); 128 and 256 time the same, 1024 is 5 % slower
 
@@ -311,8 +312,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     // The two MFMA tiles of a staged tile are worked on one after the other (fragments and presets of a tile are read up
     // front — the k-step of one fp16 product is only kQT MFMAs long: too short to hide an LDS read issued one step ahead
     // — then its MFMA chains run back to back, then its scores are filtered): one tile's fragments and accumulators live
-    // at a time keep the kernel at <= 168 VGPR, which leaves the third wave slot of every SIMD to the other kernels of
-    // the step (re-rank, solver, scoring: 120-128 VGPR) when batches overlap on several streams.
+    // at a time keep the kernel at <= 168 VGPR, i.e. three blocks per CU (two cost 18 %, alone and with the other kernels
+    // of the step overlapping on other streams: profiles/r2/filter_ablation.txt).
     // The other lane half holds the same query (its other rows): the second-largest of the union of the two halves'
     // top-2 is the tighter bound — half of the time the best two rows sit in different halves.  Once per staged tile,
     // unconditionally (some lane of the wave has a hit in nearly every staged tile; thr is the same in both halves; a bound
