@@ -249,9 +249,8 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
                                                         int max_iters, double* __restrict__ pose, double* __restrict__ rms,
                                                         int32_t* __restrict__ iters_out) {
     constexpr int NW = NT / 64;
-    __shared__ double red[NW][28];
+    __shared__ double red[NW][28], red_cnt[NW];
     __shared__ double sh_R[9], sh_t[3], sh_Rc[9], sh_tc[3];
-    __shared__ double sh_cost;
     __shared__ int sh_flag;                      // 0 continue, 1 converged/stop
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
@@ -267,17 +266,19 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
     }
     __syncthreads();
 
-    double lambda = 1e-3, cost = 0.0;
-    int it = 0;
-    for (; it < max_iters; ++it) {
-        if (sh_flag) break;
-        // ---- pass 1: normal equations at the current pose
+    // One pass over the points per LM iteration: the normal equations are accumulated AT THE CANDIDATE together with its
+    // cost.  An accepted candidate (the rule) brings the sums of the next iteration with it; after a rejected one the old
+    // sums are solved again with a larger lambda — no pass at all.  (Two passes per iteration, normal equations at the
+    // current pose and cost at the candidate, computed the same numbers 1.4 times as expensively.)
+    __shared__ double sh_s[28], sh_n[28];
+    __shared__ double sh_cnt;
+    auto sums_at = [&](const double* Rs, const double* ts, double* out, bool count) {
         double R[9], t[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = sh_R[k];
+        for (int k = 0; k < 9; ++k) R[k] = Rs[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) t[k] = sh_t[k];
-        double acc[28];
+        for (int k = 0; k < 3; ++k) t[k] = ts[k];
+        double acc[28], cnt = 0.0;
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[k] = 0.0;
         for (int i = tid; i < nv; i += NT) {
@@ -293,25 +294,44 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
 #pragma unroll
             for (int a = 0; a < 6; ++a) acc[21 + a] += J[0][a] * ru + J[1][a] * rv;
             acc[27] += ru * ru + rv * rv;
+            cnt += 1.0;
         }
 #pragma unroll
         for (int k = 0; k < 28; ++k) acc[k] = wave_sum(acc[k]);
-        if (lane == 0)
+        if (count) cnt = wave_sum(cnt);
+        __syncthreads();                            // everybody is done with red[] and with *out of the previous use
+        if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < 28; ++k) red[wave][k] = acc[k];
+            if (count) red_cnt[wave] = cnt;
+        }
         __syncthreads();
+        if (tid < 28) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += red[w][tid];
+            out[tid] = v;
+        }
+        if (count && tid == 32) {
+            double v = 0.0;
+            for (int w = 0; w < NW; ++w) v += red_cnt[w];
+            sh_cnt = v;
+        }
+        __syncthreads();
+    };
+    sums_at(sh_R, sh_t, sh_s, true);
+
+    double lambda = 1e-3;
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        const int stop = sh_flag;
+        __syncthreads();                            // thread 0 rewrites the flag below
+        if (stop) break;
         if (tid == 0) {
             // every loop of this serial part is unrolled on constant indices: the small matrices stay in registers
             // (dynamic indexing put them in scratch memory — an L2 round trip per access)
             double s[28];
 #pragma unroll
-            for (int k = 0; k < 28; ++k) {
-                s[k] = 0.0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) s[k] += red[w][k];
-            }
-            cost = s[27];
-            sh_cost = cost;
+            for (int k = 0; k < 28; ++k) s[k] = sh_s[k];
             // damped system (Marquardt scaling), Cholesky
             double A[6][6], g[6], L[6][6], dlt[6];
             {
@@ -363,35 +383,13 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
                 for (int a = 0; a < 6; ++a) n2 += dlt[a] * dlt[a];
                 sh_flag = (n2 < 1e-26) ? 1 : 0;
             } else {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) sh_Rc[k] = sh_R[k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) sh_tc[k] = sh_t[k];
                 sh_flag = 2;                                   // not positive definite: just raise lambda
             }
         }
         __syncthreads();
-        // ---- pass 2: cost at the candidate
-        double Rc[9], tc[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) Rc[k] = sh_Rc[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tc[k] = sh_tc[k];
-        double c2 = 0.0;
-        for (int i = tid; i < nv; i += NT) {
-            double ru, rv;
-            float X3[3], m2[2];
-            if (!pts.get(b, N, i, X3, m2)) continue;
-            lm_point(Rc, tc, cam, X3, m2, ru, rv, nullptr);
-            c2 += ru * ru + rv * rv;
-        }
-        c2 = wave_sum(c2);
-        if (lane == 0) red[wave][0] = c2;
-        __syncthreads();
-        double cnew = 0.0;
-        for (int w = 0; w < NW; ++w) cnew += red[w][0];
-        const double cold = sh_cost;
         const int flag = sh_flag;
+        if (flag != 2) sums_at(sh_Rc, sh_tc, sh_n, false);    // uniform: every thread sees the same flag
+        const double cold = sh_s[27], cnew = sh_n[27];
         __syncthreads();
         if (flag != 2 && cnew < cold) {                        // uniform decision: every thread sees the same numbers
             if (tid == 0) {
@@ -399,39 +397,16 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
                 for (int k = 0; k < 3; ++k) sh_t[k] = sh_tc[k];
                 if ((cold - cnew) <= 1e-14 * fmax(cold, 1e-300)) sh_flag = 1;
             }
+            if (tid < 28) sh_s[tid] = sh_n[tid];
             lambda = fmax(lambda * 0.1, 1e-12);
-            cost = cnew;
         } else {
             lambda *= 10.0;
-            cost = cold;
             if (tid == 0) sh_flag = (lambda > 1e12 || flag == 1) ? 1 : 0;
         }
         __syncthreads();
     }
-    // ---- cost at the pose that is returned (also covers max_iters == 0 and early stops)
-    double n_used = 0.0;
-    {
-        double R[9], t[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = sh_R[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) t[k] = sh_t[k];
-        double c2 = 0.0, cnt = 0.0;
-        for (int i = tid; i < nv; i += NT) {
-            double ru, rv;
-            float X3[3], m2[2];
-            if (!pts.get(b, N, i, X3, m2)) continue;
-            lm_point(R, t, cam, X3, m2, ru, rv, nullptr);
-            c2 += ru * ru + rv * rv;
-            cnt += 1.0;
-        }
-        c2 = wave_sum(c2);
-        cnt = wave_sum(cnt);
-        if (lane == 0) { red[wave][0] = c2; red[wave][1] = cnt; }
-        __syncthreads();
-        cost = 0.0; n_used = 0.0;
-        for (int w = 0; w < NW; ++w) { cost += red[w][0]; n_used += red[w][1]; }
-    }
+    // the sums at the pose that is returned carry its cost (also with max_iters == 0 and after early stops)
+    const double cost = sh_s[27], n_used = sh_cnt;
     if (tid == 0) {
         if (it > 0) {                               // no iteration ran: the caller's pose stays bit-for-bit
             double R[9], w[3];
