@@ -25,12 +25,19 @@ for B, N in ((32, 65536), (64, 176)):
     X, Y, Z, u, v = f(Xw[..., 0]), f(Xw[..., 1]), f(Xw[..., 2]), f(uv[..., 0]), f(uv[..., 1])
     m = torch.from_numpy(words).to(dev) if words is not None else None
     p0 = torch.from_numpy(pose0).to(dev); k4 = torch.from_numpy(K4).to(dev)
-    ts = []
-    for k in range(6):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
-        pose, rms, iters = ransac.refine_pose_lm_soa(X, Y, Z, u, v, p0, k4, mask=m, max_iters=30)
-        e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
-    h = hashlib.sha1(pose.cpu().numpy().tobytes() + rms.cpu().numpy().tobytes() + iters.cpu().numpy().tobytes()).hexdigest()[:12]
-    it = iters.cpu().numpy()
-    print(f"B={B} N={N}: {np.mean(ts[1:]):8.1f} us  iters {it.min()}..{it.max()} (mean {it.mean():.1f})  rms {float(rms.mean()):.4f}  sha1 {h}")
+    ref = None
+    for blocks in ("one", "auto"):
+        ts = []
+        for k in range(6):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            pose, rms, iters = ransac.refine_pose_lm_soa(X, Y, Z, u, v, p0, k4, mask=m, max_iters=30, blocks=blocks)
+            e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1) * 1e3)
+        h = hashlib.sha1(pose.cpu().numpy().tobytes() + rms.cpu().numpy().tobytes() + iters.cpu().numpy().tobytes()).hexdigest()[:12]
+        it = iters.cpu().numpy()
+        d = "" if ref is None else f"  max |pose - one| {float((pose - ref[0]).abs().max()):.2e}  iters equal {bool((iters == ref[1]).all())}"
+        if ref is not None and not bool((iters == ref[1]).all()):
+            print("   iters one :", ref[1].cpu().numpy().tolist()); print("   iters auto:", it.tolist())
+        if ref is None:
+            ref = (pose, iters)
+        print(f"B={B} N={N} blocks={blocks}: {np.mean(ts[1:]):8.1f} us  iters {it.min()}..{it.max()} (mean {it.mean():.1f})  rms {float(rms.mean()):.4f}  sha1 {h}{d}")

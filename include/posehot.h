@@ -348,6 +348,17 @@ int ph_refine_pose_lm_soa(const float* X, const float* Y, const float* Z, const 
                           const double* K4, const double* dist5, int max_iters,
                           double* pose, double* rms, int32_t* iters, void* stream);
 
+/* The same refinement with several blocks per item for LARGE point sets (one block per item leaves all but B of the
+ * 256 CUs idle): every LM iteration is one launch over (blocks per item) x B blocks, max_iters + 2 launches per call,
+ * state and partial sums in the workspace (ph_refine_pose_lm_soa_ws_bytes; 0 = the point sets are small or the batch is
+ * large enough, and the call is ph_refine_pose_lm_soa itself).  Same iteration, same stopping rules; the sums are added in
+ * another order, so the poses of the two entry points agree to rounding (1e-9), not bit for bit.  Deterministic. */
+size_t ph_refine_pose_lm_soa_ws_bytes(int B, int N);
+int ph_refine_pose_lm_soa_ws(const float* X, const float* Y, const float* Z, const float* u, const float* v,
+                             const uint64_t* mask, const int32_t* n_valid, int B, int N,
+                             const double* K4, const double* dist5, int max_iters,
+                             double* pose, double* rms, int32_t* iters, void* ws, size_t ws_bytes, void* stream);
+
 /* Initial pose of coplanar (z = 0) point sets from the plane-to-image homography: the first half of
  * cv2.solvePnP(..., SOLVEPNP_ITERATIVE) on board points (main.py:101-104 == validate_pose.py:93-96; the algorithm inside OpenCV,
  * restated: normalised DLT on undistorted points, decomposition, nearest rotation) — what ph_refine_pose_lm starts from.

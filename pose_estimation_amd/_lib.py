@@ -70,6 +70,8 @@ SIGNATURES = {
     "ph_reprojection_error": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "ph_refine_pose_lm": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "ph_refine_pose_lm_soa": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
+    "ph_refine_pose_lm_soa_ws_bytes": (_sz, [_i, _i]),
+    "ph_refine_pose_lm_soa_ws": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _sz, _p]),
     "ph_pose_from_projection": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ph_initial_board_pose": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _p]),
     "ph_camera_from_pose": (_i, [_p, _i, _p, _p]),

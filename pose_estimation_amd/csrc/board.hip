@@ -222,6 +222,60 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// One damped step from the sums s = (J'J upper triangle [21], J'r [6], cost): the candidate pose (Rn, tn).  Returns 0,
+// 1 when the step is too small to matter (the candidate is still tried), 2 when the damped system is not positive
+// definite (no candidate: the caller raises lambda).  Every loop is unrolled on constant indices: the small matrices
+// stay in registers (dynamic indexing put them in scratch memory — an L2 round trip per access).
+__device__ __forceinline__ int lm_solve(const double (&s)[28], double lambda, const double (&Rcur)[9], const double (&tcur)[3],
+                                        double (&Rn)[9], double (&tn)[3]) {
+    // damped system (Marquardt scaling), Cholesky
+    double A[6][6], g[6], L[6][6], dlt[6];
+    {
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) { A[a][c] = s[q]; A[c][a] = s[q]; ++q; }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) { g[a] = -s[21 + a]; A[a][a] += lambda * A[a][a] + 1e-300; }
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = 0; c <= a; ++c) {
+            double v = A[a][c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
+            if (a == c) { ok = ok && (v > 0.0); L[a][a] = sqrt(fmax(v, 1e-300)); }
+            else L[a][c] = v / L[c][c];
+        }
+    if (!ok) return 2;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double v = g[a];
+#pragma unroll
+        for (int k = 0; k < a; ++k) v -= L[a][k] * dlt[k];
+        dlt[a] = v / L[a][a];
+    }
+#pragma unroll
+    for (int a = 5; a >= 0; --a) {
+        double v = dlt[a];
+#pragma unroll
+        for (int k = a + 1; k < 6; ++k) v -= L[k][a] * dlt[k];
+        dlt[a] = v / L[a][a];
+    }
+    double dR[9];
+    exp_so3(dlt, dR);
+    mat3_mul(dR, Rcur, Rn);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tn[k] = tcur[k] + dlt[3 + k];
+    double n2 = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) n2 += dlt[a] * dlt[a];
+    return (n2 < 1e-26) ? 1 : 0;
+}
+
 // Point sources of the refinement kernel: the board path hands over interleaved rows (obj [B][N][3], img [B][N][2]),
 // the RANSAC path SoA rows [B][N] plus the winning hypothesis' inlier mask.
 struct PointsAoS {
@@ -327,64 +381,21 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
         __syncthreads();                            // thread 0 rewrites the flag below
         if (stop) break;
         if (tid == 0) {
-            // every loop of this serial part is unrolled on constant indices: the small matrices stay in registers
-            // (dynamic indexing put them in scratch memory — an L2 round trip per access)
-            double s[28];
+            double s[28], Rcur[9], tcur[3], Rn[9], tn[3];
 #pragma unroll
             for (int k = 0; k < 28; ++k) s[k] = sh_s[k];
-            // damped system (Marquardt scaling), Cholesky
-            double A[6][6], g[6], L[6][6], dlt[6];
-            {
-                int q = 0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a)
+            for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
 #pragma unroll
-                    for (int c = a; c < 6; ++c) { A[a][c] = s[q]; A[c][a] = s[q]; ++q; }
-            }
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { g[a] = -s[21 + a]; A[a][a] += lambda * A[a][a] + 1e-300; }
-            bool ok = true;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int c = 0; c <= a; ++c) {
-                    double v = A[a][c];
-#pragma unroll
-                    for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
-                    if (a == c) { ok = ok && (v > 0.0); L[a][a] = sqrt(fmax(v, 1e-300)); }
-                    else L[a][c] = v / L[c][c];
-                }
-            if (ok) {
-#pragma unroll
-                for (int a = 0; a < 6; ++a) {
-                    double v = g[a];
-#pragma unroll
-                    for (int k = 0; k < a; ++k) v -= L[a][k] * dlt[k];
-                    dlt[a] = v / L[a][a];
-                }
-#pragma unroll
-                for (int a = 5; a >= 0; --a) {
-                    double v = dlt[a];
-#pragma unroll
-                    for (int k = a + 1; k < 6; ++k) v -= L[k][a] * dlt[k];
-                    dlt[a] = v / L[a][a];
-                }
-                double dR[9], Rn[9], Rcur[9];
-                exp_so3(dlt, dR);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) Rcur[k] = sh_R[k];
-                mat3_mul(dR, Rcur, Rn);
+            for (int k = 0; k < 3; ++k) tcur[k] = sh_t[k];
+            const int f = lm_solve(s, lambda, Rcur, tcur, Rn, tn);
+            if (f != 2) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) sh_Rc[k] = Rn[k];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) sh_tc[k] = sh_t[k] + dlt[3 + k];
-                double n2 = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a) n2 += dlt[a] * dlt[a];
-                sh_flag = (n2 < 1e-26) ? 1 : 0;
-            } else {
-                sh_flag = 2;                                   // not positive definite: just raise lambda
+                for (int k = 0; k < 3; ++k) sh_tc[k] = tn[k];
             }
+            sh_flag = f;
         }
         __syncthreads();
         const int flag = sh_flag;
@@ -417,6 +428,178 @@ __global__ __launch_bounds__(NT) void refine_pose_kernel(const Pts pts, const in
         if (rms) rms[b] = n_used > 0.0 ? sqrt(cost / n_used) : 0.0;
         if (iters_out) iters_out[b] = it;
     }
+}
+
+// ---- the same iteration with G blocks per item, for large point sets (one block per item leaves all but B of the 256 CUs
+// idle: 2.05 ms at 32 items of 65 536 points).  No grid-wide barrier: every LM iteration is one launch.  Launch k finishes
+// the iteration whose pass launch k-1 made (sums the G partial sums in a fixed order, accepts or rejects the candidate),
+// solves for the next candidate and makes its pass; every block of an item does the few microseconds of serial work
+// redundantly (same inputs, same instructions, same numbers) and block 0 records the state for the next launch.  State
+// and partial sums are double-buffered in the workspace, so a launch never reads what it writes.  Deterministic; the sums
+// are added in another order than in the one-block kernel, so the two agree to rounding, not bit for bit.
+struct LmState {
+    double R[9], t[3], Rc[9], tc[3], s[28], lambda, cnt;
+    int it, stop, pflag, pad;        // pflag: result of lm_solve for the iteration in flight (0, 1, 2); -1: the initial sums
+};                                   //        are in flight; -2: finished (nothing in flight, nothing more to do)
+constexpr int kLmPart = 32;          // doubles per partial record: 28 sums, the point count, padding
+constexpr int kLmNT = 512;
+
+// finishes the iteration in flight from the summed partials n[0..28], then starts the next one unless `last`
+__device__ __forceinline__ void lm_advance(LmState& st, const double* n, int max_iters, bool last) {
+    if (st.pflag == -2) return;
+    if (st.pflag == -1) {
+#pragma unroll
+        for (int k = 0; k < 28; ++k) st.s[k] = n[k];
+        st.cnt = n[28];
+    } else {
+        const double cold = st.s[27], cnew = n[27];
+        if (st.pflag != 2 && cnew < cold) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) st.R[k] = st.Rc[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) st.t[k] = st.tc[k];
+#pragma unroll
+            for (int k = 0; k < 28; ++k) st.s[k] = n[k];
+            st.stop = (st.pflag == 1 || (cold - cnew) <= 1e-14 * fmax(cold, 1e-300)) ? 1 : 0;
+            st.lambda = fmax(st.lambda * 0.1, 1e-12);
+        } else {
+            st.lambda *= 10.0;
+            st.stop = (st.lambda > 1e12 || st.pflag == 1) ? 1 : 0;
+        }
+        st.it += 1;
+    }
+    if (last || st.stop || st.it >= max_iters) { st.pflag = -2; return; }
+    st.pflag = lm_solve(st.s, st.lambda, st.R, st.t, st.Rc, st.tc);
+}
+
+template <class Pts>
+__global__ __launch_bounds__(kLmNT) void refine_pose_step_kernel(const Pts pts, const int32_t* __restrict__ n_valid, int N, int G,
+                                                                int chunk, const double* __restrict__ K4,
+                                                                const double* __restrict__ d5, int max_iters, int k, int B,
+                                                                const double* __restrict__ pose, LmState* __restrict__ state,
+                                                                double* __restrict__ part) {
+    constexpr int NW = kLmNT / 64;
+    __shared__ LmState st;
+    __shared__ double nsum[kLmPart];
+    __shared__ double red[NW][29];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = n_valid ? min(max(n_valid[b], 0), N) : N;
+    const LmState* prev = state + (size_t)((k + 1) & 1) * B + b;
+    LmState* next = state + (size_t)(k & 1) * B + b;
+    if (k > 0) {
+        if (prev->pflag == -2) {                    // uniform: nothing in flight; keep the record moving
+            if (g == 0 && tid == 0) *next = *prev;
+            return;
+        }
+        if (tid < 29) {                             // the G partial records of the pass in flight, in block order
+            const double* pp = part + ((size_t)((k + 1) & 1) * B + b) * G * kLmPart + tid;
+            double v = 0.0;
+            if (prev->pflag != 2)
+                for (int q = 0; q < G; ++q) v += pp[(size_t)q * kLmPart];
+            nsum[tid] = v;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (k == 0) {
+            const double* P = pose + (size_t)b * 6;
+            double R0[9];
+            rodrigues(P, R0);
+#pragma unroll
+            for (int q = 0; q < 9; ++q) { st.R[q] = R0[q]; st.Rc[q] = R0[q]; }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { st.t[q] = P[3 + q]; st.tc[q] = P[3 + q]; }
+#pragma unroll
+            for (int q = 0; q < 28; ++q) st.s[q] = 0.0;
+            st.lambda = 1e-3; st.cnt = 0.0; st.it = 0; st.stop = (nv < 3) ? 1 : 0; st.pflag = -1; st.pad = 0;
+        } else {
+            LmState w = *prev;
+            lm_advance(w, nsum, max_iters, false);
+            st = w;
+        }
+        if (g == 0) *next = st;
+    }
+    __syncthreads();
+    if (st.pflag == -2 || st.pflag == 2) return;   // uniform: finished, or no candidate to try
+    const Cam cam = load_cam(K4, d5);
+    double R[9], t[3];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) R[q] = st.Rc[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) t[q] = st.tc[q];
+    double acc[29];
+#pragma unroll
+    for (int q = 0; q < 29; ++q) acc[q] = 0.0;
+    const int i1 = min(nv, (g + 1) * chunk);
+    for (int i = g * chunk + tid; i < i1; i += kLmNT) {
+        double ru, rv, J[2][6];
+        float X3[3], m2[2];
+        if (!pts.get(b, N, i, X3, m2)) continue;
+        lm_point(R, t, cam, X3, m2, ru, rv, J);
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c) acc[q++] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += J[0][a] * ru + J[1][a] * rv;
+        acc[27] += ru * ru + rv * rv;
+        acc[28] += 1.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 29; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < 29; ++q) red[wave][q] = acc[q];
+    __syncthreads();
+    if (tid < 29) {
+        double v = 0.0;
+        for (int w = 0; w < NW; ++w) v += red[w][tid];
+        part[(((size_t)(k & 1) * B + b) * G + g) * kLmPart + tid] = v;
+    }
+}
+
+// after the last step launch (index k_last): finishes the iteration in flight and writes the results
+__global__ __launch_bounds__(64) void refine_pose_finish_kernel(int G, int max_iters, int k_last, int B,
+                                                               const LmState* __restrict__ state, const double* __restrict__ part,
+                                                               double* __restrict__ pose, double* __restrict__ rms,
+                                                               int32_t* __restrict__ iters_out) {
+    __shared__ double nsum[kLmPart];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const LmState* prev = state + (size_t)(k_last & 1) * B + b;
+    if (tid < 29) {
+        const double* pp = part + ((size_t)(k_last & 1) * B + b) * G * kLmPart + tid;
+        double v = 0.0;
+        if (prev->pflag != 2 && prev->pflag != -2)
+            for (int q = 0; q < G; ++q) v += pp[(size_t)q * kLmPart];
+        nsum[tid] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    LmState w = *prev;
+    lm_advance(w, nsum, max_iters, true);
+    if (w.it > 0) {                                 // no iteration ran: the caller's pose stays bit-for-bit
+        double* P = pose + (size_t)b * 6;
+        double rv[3];
+        log_so3(w.R, rv);
+        P[0] = rv[0]; P[1] = rv[1]; P[2] = rv[2]; P[3] = w.t[0]; P[4] = w.t[1]; P[5] = w.t[2];
+    }
+    if (rms) rms[b] = w.cnt > 0.0 ? sqrt(w.s[27] / w.cnt) : 0.0;
+    if (iters_out) iters_out[b] = w.it;
+}
+
+struct LmPlan { int G, chunk; size_t off_part, total; };
+LmPlan plan_lm(int B, int N) {
+    LmPlan p;
+    int G = 256 / (B > 0 ? B : 1);                  // one block per CU
+    if (G > 16) G = 16;
+    if (G > N / 4096) G = N / 4096;                 // at least 4096 points per block
+    if (G < 1) G = 1;
+    p.G = G;
+    p.chunk = (ph_ceil_div(N > 0 ? N : 1, G) + 63) / 64 * 64;
+    p.off_part = (sizeof(LmState) * 2 * (size_t)(B > 0 ? B : 0) + 255) / 256 * 256;
+    p.total = G > 1 ? p.off_part + sizeof(double) * 2 * (size_t)B * G * kLmPart : 0;
+    return p;
 }
 
 // Winning 3x4 hypothesis -> (rvec, tvec): undo K when given, project the 3x3 block onto SO(3) (one Newton step of the
@@ -724,6 +907,33 @@ extern "C" int ph_refine_pose_lm_soa(const float* X, const float* Y, const float
     else
         hipLaunchKernelGGL((refine_pose_kernel<PointsSoA, 512>), dim3(B), dim3(512), 0, (hipStream_t)stream, pts, n_valid,
                            N, K4, dist5, max_iters, pose, rms, iters);
+    return ph_launch_status();
+}
+
+extern "C" size_t ph_refine_pose_lm_soa_ws_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return plan_lm(B, N).total;
+}
+
+extern "C" int ph_refine_pose_lm_soa_ws(const float* X, const float* Y, const float* Z, const float* u, const float* v,
+                                        const uint64_t* mask, const int32_t* n_valid, int B, int N, const double* K4,
+                                        const double* dist5, int max_iters, double* pose, double* rms, int32_t* iters,
+                                        void* ws, size_t ws_bytes, void* stream) {
+    if (B < 0 || N < 0 || max_iters < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    const LmPlan p = plan_lm(B, N);
+    if (p.G <= 1 || B > 65535)                      // small point sets: the one-block kernel, no workspace
+        return ph_refine_pose_lm_soa(X, Y, Z, u, v, mask, n_valid, B, N, K4, dist5, max_iters, pose, rms, iters, stream);
+    if (!pose || !K4 || !dist5 || !X || !Y || !Z || !u || !v) return PH_ERR_INVALID_ARG;
+    if (!ws || ws_bytes < p.total) return PH_ERR_WORKSPACE;
+    const PointsSoA pts{X, Y, Z, u, v, mask, (N + 63) / 64};
+    LmState* state = (LmState*)ws;
+    double* part = (double*)((char*)ws + p.off_part);
+    for (int k = 0; k <= max_iters; ++k)
+        hipLaunchKernelGGL((refine_pose_step_kernel<PointsSoA>), dim3(p.G, B), dim3(kLmNT), 0, (hipStream_t)stream, pts, n_valid, N,
+                           p.G, p.chunk, K4, dist5, max_iters, k, B, pose, state, part);
+    hipLaunchKernelGGL(refine_pose_finish_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, p.G, max_iters, max_iters, B, state,
+                       part, pose, rms, iters);
     return ph_launch_status();
 }
 

@@ -186,9 +186,15 @@ def pose_from_projection(P, sel=None, K4=None):
     return pose
 
 
-def refine_pose_lm_soa(X, Y, Z, u, v, pose, K4, dist5=None, mask=None, n_valid=None, max_iters=30):
-    """Levenberg-Marquardt on the reprojection error over the masked points (float64, one block per item).
-    Returns (pose ``[B, 6]``, rms ``[B]``, iters ``[B]``); the input pose tensor is not modified."""
+def refine_pose_lm_soa(X, Y, Z, u, v, pose, K4, dist5=None, mask=None, n_valid=None, max_iters=30, blocks="auto"):
+    """Levenberg-Marquardt on the reprojection error over the masked points (float64).
+    Returns (pose ``[B, 6]``, rms ``[B]``, iters ``[B]``); the input pose tensor is not modified.
+
+    blocks="auto": large point sets in small batches run several blocks per item, one launch per iteration
+    (``ph_refine_pose_lm_soa_ws``); "one": always the one-block-per-item kernel (``ph_refine_pose_lm_soa``).  The two agree
+    to rounding."""
+    if blocks not in ("auto", "one"):
+        raise ValueError("blocks must be 'auto' or 'one'")
     lib = L.load()
     X, Y, Z, u, v = _pts((X, Y, Z, u, v), ("X", "Y", "Z", "u", "v"))
     B, N = X.shape
@@ -202,6 +208,13 @@ def refine_pose_lm_soa(X, Y, Z, u, v, pose, K4, dist5=None, mask=None, n_valid=N
     n_valid = L.opt_i32(n_valid, B, "n_valid")
     rms = torch.empty((B,), dtype=torch.float64, device=X.device)
     iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+    nws = int(lib.ph_refine_pose_lm_soa_ws_bytes(B, N)) if blocks == "auto" else 0
+    if nws > 0:
+        ws = L.workspace(nws, X.device)
+        L.check(lib.ph_refine_pose_lm_soa_ws(L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(mask), L.ptr(n_valid), B, N,
+                                             L.ptr(K4), L.ptr(dist5), int(max_iters), L.ptr(pose), L.ptr(rms), L.ptr(iters),
+                                             L.ptr(ws), nws, L.stream_ptr()), "ph_refine_pose_lm_soa_ws")
+        return pose, rms, iters
     L.check(lib.ph_refine_pose_lm_soa(L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v), L.ptr(mask), L.ptr(n_valid), B, N,
                                       L.ptr(K4), L.ptr(dist5), int(max_iters), L.ptr(pose), L.ptr(rms), L.ptr(iters),
                                       L.stream_ptr()), "ph_refine_pose_lm_soa")

@@ -91,3 +91,51 @@ def test_camera_from_pose_matches_reference_function_and_goldens(device):
         # largest component is itself within that loss of zero
         g = quats[b][[3, 0, 1, 2]]
         assert np.abs(cam["quaternion"][b] - g).max() < 1e-7
+
+
+def test_refine_pose_several_blocks_per_item_equals_one_block(device):
+    """ph_refine_pose_lm_soa_ws (one launch per LM iteration, several blocks per item) against ph_refine_pose_lm_soa and the
+    oracle's NumPy LM: ragged n_valid (an item whose later blocks have no points, an item below three points), an inlier
+    mask, max_iters = 0, and the workspace check."""
+    from pose_estimation_amd import _lib as L
+    B, N = 3, 16384
+    fr = synthetic.pnp_frames(B, N, outliers=0.0, noise_px=1.0, seed=77)
+    rng = np.random.default_rng(3)
+    n_valid = np.array([N, 5000, 2], np.int32)
+    bits = rng.random((B, N)) < 0.7
+    mask = np.packbits(bits.reshape(B, -1, 64), axis=-1, bitorder="little").view(np.uint64).reshape(B, -1)
+    pose0 = np.stack([np.concatenate([board.rotation_to_rvec(fr["R"][b]), fr["t"][b]]) for b in range(B)])
+    pose0 += rng.normal(0, 0.01, pose0.shape)
+    pts = [_t(fr[k], device) for k in "XYZuv"]
+    K4 = _t(orc.K4, device)
+    lib = L.load()
+    assert lib.ph_refine_pose_lm_soa_ws_bytes(B, N) > 0 and lib.ph_refine_pose_lm_soa_ws_bytes(B, 4096) == 0
+    assert lib.ph_refine_pose_lm_soa_ws_bytes(256, N) == 0          # a batch that fills the chip with one block per item
+    args = dict(mask=_t(mask.view(np.int64), device), n_valid=_t(n_valid, device), max_iters=30)
+    p1, r1, i1 = ransac.refine_pose_lm_soa(*pts, _t(pose0, device), K4, blocks="one", **args)
+    p2, r2, i2 = ransac.refine_pose_lm_soa(*pts, _t(pose0, device), K4, blocks="auto", **args)
+    p1, r1, i1, p2, r2, i2 = (x.cpu().numpy() for x in (p1, r1, i1, p2, r2, i2))
+    assert np.abs(p1 - p2).max() < 1e-9 and np.abs(r1 - r2).max() < 1e-9
+    assert i2[2] == 0 and np.array_equal(p2[2], pose0[2])            # below three points: nothing runs, pose bit for bit
+    assert (i2[:2] > 0).all() and (i2 <= 30).all()
+    for b in range(2):
+        nv = int(n_valid[b])
+        inl = bits[b, :nv]
+        obj = np.stack([fr[k][b, :nv] for k in "XYZ"], axis=1)[inl]; img = np.stack([fr[k][b, :nv] for k in "uv"], axis=1)[inl]
+        rp, rrms = orc.refine_pose_lm_np(obj, img, pose0[b], dist=np.zeros(5), max_iters=100)
+        assert geometry.rotation_angle_deg(board.rodrigues(p2[b, :3]), board.rodrigues(rp[:3])) < 1e-4
+        assert np.abs(p2[b, 3:] - rp[3:]).max() < 1e-6 and abs(r2[b] - rrms) < 1e-7
+    # no iteration: the pose comes back bit for bit, rms is the cost of the start pose (both paths)
+    a0 = dict(args, max_iters=0)
+    q1, s1, j1 = ransac.refine_pose_lm_soa(*pts, _t(pose0, device), K4, blocks="one", **a0)
+    q2, s2, j2 = ransac.refine_pose_lm_soa(*pts, _t(pose0, device), K4, blocks="auto", **a0)
+    assert np.array_equal(q2.cpu().numpy(), pose0) and np.array_equal(q1.cpu().numpy(), pose0)
+    assert (j2.cpu().numpy() == 0).all() and np.abs(s1.cpu().numpy() - s2.cpu().numpy()).max() < 1e-9
+    assert (s2.cpu().numpy()[:2] > r2[:2]).all()
+    # a workspace that is too small is refused before anything is launched
+    pose = _t(pose0, device).clone(); ws = torch.empty(64, dtype=torch.uint8, device=device)
+    st = lib.ph_refine_pose_lm_soa_ws(*(L.ptr(t) for t in pts), None, None, B, N, L.ptr(K4), L.ptr(torch.zeros(5, dtype=torch.float64, device=device)),
+                                      5, L.ptr(pose), None, None, L.ptr(ws), 64, L.stream_ptr())
+    assert st == -3
+    torch.cuda.synchronize()
+    assert np.array_equal(pose.cpu().numpy(), pose0)
