@@ -128,13 +128,21 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, split = blockIdx.y;
+    // Block -> (pair, split, query block).  Blocks are dispatched in linear id order, round-robin over the 8 XCDs, each with
+    // its own L2: all blocks of a pair get ids of one residue mod 8, so a pair's tile images stream through ONE L2
+    // (match_l2_filter.hip does the same).
+    const unsigned gx = gridDim.x, per_pair = gridDim.x * gridDim.y, nb = gridDim.z;
+    const unsigned id = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+    unsigned bb, rr;
+    if (id < (nb & ~7u) * per_pair) { const unsigned i = id >> 3; bb = (id & 7u) + 8u * (i / per_pair); rr = i % per_pair; }   // whole groups of 8 pairs
+    else { bb = id / per_pair; rr = id % per_pair; }
+    const int b = (int)bb, split = (int)(rr / gx), xq = (int)(rr % gx);
     const int vq = view_q ? view_q[b] : b;
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
     const uint4* Q = dq + (size_t)vq * nq * 2;
     const uint4* IMG = img + (size_t)b * tiles * kHImg;
-    const int qw0 = (blockIdx.x * 4 + wave) * (32 * QT);
+    const int qw0 = (xq * 4 + wave) * (32 * QT);
 
     uint4 bq[QT][4];
     int bi[QT];
