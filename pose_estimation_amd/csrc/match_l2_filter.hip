@@ -229,7 +229,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     // all blocks of a pair are given ids of one residue mod 8, so a pair's train view is streamed through ONE L2.
     const int per_pair = nqb * (slots / 2);
     int b, rr;
-    if ((B & 7) == 0) {
+    if (blockIdx.x < (unsigned)((B & ~7) * per_pair)) {          // whole groups of 8 pairs
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
         b = xcd + 8 * (i / per_pair); rr = i % per_pair;
     } else {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     constexpr int QPB = 256 / kRL;
     const int bpp = (nq + QPB - 1) / QPB;                 // blocks per pair
     int b, bq;
-    if ((B & 7) == 0) {
+    if (blockIdx.x < (unsigned)((B & ~7) * bpp)) {          // whole groups of 8 pairs
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
         b = xcd + 8 * (i / bpp); bq = i % bpp;
     } else {
