@@ -925,7 +925,7 @@ extern "C" int ph_refine_pose_lm_soa_ws(const float* X, const float* Y, const fl
     if (p.G <= 1 || B > 65535)                      // small point sets: the one-block kernel, no workspace
         return ph_refine_pose_lm_soa(X, Y, Z, u, v, mask, n_valid, B, N, K4, dist5, max_iters, pose, rms, iters, stream);
     if (!pose || !K4 || !dist5 || !X || !Y || !Z || !u || !v) return PH_ERR_INVALID_ARG;
-    if (!ws || ws_bytes < p.total) return PH_ERR_WORKSPACE;
+    if (!ws || ws_bytes < p.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
     const PointsSoA pts{X, Y, Z, u, v, mask, (N + 63) / 64};
     LmState* state = (LmState*)ws;
     double* part = (double*)((char*)ws + p.off_part);
