@@ -52,7 +52,7 @@ constexpr int kMR = 32;                           // train rows per MFMA tile
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float kNoScoreF = -1.0e9f;              // exactly representable, below every real score (>= -256); its own floor
-constexpr float kTopFrac = 15.0f / 16.0f;         // the largest row fraction of a key: key > score + kTopFrac <=> a larger score
+constexpr float kTopFrac = 0.75f;                 // the largest group fraction of a key: key > score + kTopFrac <=> a larger score
 
 // 8 bits -> 8 nibbles, bit i at bit 4i
 __device__ __forceinline__ uint32_t spread8(uint32_t x) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int splits, int rows_per_split,
     int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
-    uint2* __restrict__ partial) {
+    uint2* __restrict__ partial, const uint4* __restrict__ dt_raw, const int32_t* __restrict__ view_t) {
     __shared__ uint4 smem[3 * kHImg];             // ring of three staged tiles (ONE LDS object beside the DMA target)
     static_assert(kHImgRows % 256 == 0, "staging deal");
     constexpr int kGlds = kHImgRows / 256;        // LDS-DMA instructions per wave per staged tile
@@ -161,12 +161,20 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     const int t_begin = split * rows_per_split;          // a multiple of kHSR
     const int t_end = min(ntv, t_begin + rows_per_split);
 
-    // When some lane's score beats the entry bound, the scan's 16 scores are turned into keys that carry their row:
-    // key = q.t + (15 - r) / 16 for accumulator register r — q.t is an even integer, the fraction orders equal scores of ONE
-    // scan by row (registers are in increasing row order) and floor() gives the score back.  Keeping a scan's best two keys
-    // is then two instructions per row (max, med3) with no index bookkeeping; the running best of the lane remembers its
-    // tile.  Across scans the comparison is on scores alone (strict '>': the earlier tile keeps a tie).
+    // Top-2 upkeep on GROUPS of four rows.  A lane's sixteen scores of a scan are four groups of four consecutive rows; when
+    // some lane's maximum beats the entry bound the four group maxima (which the entry test has computed anyway) become keys
+    // that carry their group: key = max q.t of the group + (3 - g) / 4 — q.t is an even integer, the fraction orders equal
+    // maxima of ONE scan by row order and floor() gives the score back.  The lane keeps the best two group keys seen (max +
+    // med3 per group, no index bookkeeping; the best remembers its tile); across scans the comparison is on scores alone
+    // (strict '>': the earlier tile keeps a tie).  Which row of the best group it is, and whether the group holds the
+    // runner-up as well, is settled ONCE per query after the loop from the 4 x 256 bits themselves (resolve below): every
+    // row outside the best group scores at most its group's maximum, so the runner-up is the larger of the second-best
+    // group maximum and the second-largest score inside the best group.  The hit path of a scan is 26 instructions
+    // instead of 64 (keys on all sixteen rows) or ~100 (per-row compare / select).
     auto scan = [&](const f32x16& acc, int ct, int t0) {
+#if PH_HAM_ABLATE & 2
+        if (t0 >= 0) { m1[ct] = fmaxf(m1[ct], acc[0]); return; }      // timing only: the scores are not looked at
+#endif
         float m4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) m4[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
@@ -174,20 +182,17 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
 #if PH_HAM_ABLATE & 1
         if (t0 >= 0) { m1[ct] = fmaxf(m1[ct], m4[0]); return; }     // timing only: no top-2 upkeep
 #endif
-        const float ka = acc[0] + kTopFrac, kb = acc[1] + 14.0f / 16.0f;
+        const float ka = m4[0] + kTopFrac, kb = m4[1] + 0.5f, kc = m4[2] + 0.25f, kd = m4[3];
         float k1 = fmaxf(ka, kb), k2 = fminf(ka, kb);
-#pragma unroll
-        for (int r = 2; r < 16; ++r) {
-            const float k = acc[r] + (float)(15 - r) * (1.0f / 16.0f);
-            k2 = __builtin_amdgcn_fmed3f(k1, k2, k); k1 = fmaxf(k1, k);
-        }
+        k2 = __builtin_amdgcn_fmed3f(k1, k2, kc); k1 = fmaxf(k1, kc);
+        k2 = __builtin_amdgcn_fmed3f(k1, k2, kd); k1 = fmaxf(k1, kd);
         const bool gt = k1 > floorf(m1[ct]) + kTopFrac;            // a strictly better score
-        m2[ct] = fmaxf(fmaxf(fminf(m1[ct], k1), k2), m2[ct]);      // only the score of the runner-up is ever used
+        m2[ct] = fmaxf(fmaxf(fminf(m1[ct], k1), k2), m2[ct]);      // only the score of the runner-up group is ever used
         m1[ct] = gt ? k1 : m1[ct];
         bi[ct] = gt ? t0 : bi[ct];
         // The other lane half scans the other rows of the same query.  A row can only enter the query's top-2 (ties:
         // lowest index for the best, distance only for the runner-up) if its score beats the second-largest score of BOTH
-        // halves' top-2 together, all from earlier rows — the tighter entry test, refreshed after every scan.
+        // halves' best two groups together, all from earlier rows — the entry test, refreshed after every scan.
         float l1, h1, l2, h2;
         both_halves(m1[ct], l1, h1); both_halves(m2[ct], l2, h2);
         bound[ct] = floorf(fmaxf(fminf(l1, h1), fmaxf(l2, h2)));
@@ -266,10 +271,33 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
 
 #pragma unroll
     for (int ct = 0; ct < QT; ++ct) {
-        // back to (score, row): the fraction of the best key is its accumulator register
-        const float s1 = floorf(m1[ct]), s2 = floorf(m2[ct]);
-        const int rr = 15 - (int)((m1[ct] - s1) * 16.0f);
-        const int row = bi[ct] >= 0 ? bi[ct] + 4 * h + (rr & 3) + 8 * (rr >> 2) : PH_NO_INDEX;
+        // back to (score, row): the fraction of the best key is its group; the group's four rows are scored again from
+        // their bits (the lowest row with the best score is the match; the others may hold the runner-up)
+        const int qi = qw0 + ct * 32 + li;
+        const float s1 = floorf(m1[ct]);
+        float s2 = floorf(m2[ct]);
+        int row = PH_NO_INDEX;
+        if (bi[ct] >= 0) {
+            const int grp = 3 - (int)((m1[ct] - s1) * 4.0f);
+            const int base = bi[ct] + 4 * h + 8 * grp;
+            const int vt = view_t ? view_t[b] : b;
+            const uint4* T = dt_raw + ((size_t)vt * nt) * 2;
+            const int qc = min(qi, nq - 1);
+            const uint4 qa = Q[(size_t)qc * 2], qb = Q[(size_t)qc * 2 + 1];
+            float second = kNoScoreF;
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {
+                const int j = base + r;
+                if (j >= t_end) continue;                   // padded rows of the last staged tile
+                const uint4 ta = T[(size_t)j * 2], tb = T[(size_t)j * 2 + 1];
+                const int d = __popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                              __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w);
+                const float sr = (float)(256 - 2 * d);
+                if (sr == s1) { if (row >= 0) second = s1; row = j; }     // descending r: the lowest such row stays
+                else second = fmaxf(second, sr);
+            }
+            s2 = fmaxf(s2, second);
+        }
         const float om1 = __shfl_xor(s1, 32), om2 = __shfl_xor(s2, 32);
         const int obi = __shfl_xor(row, 32);
         const bool other = (om1 > s1) || (om1 == s1 && obi >= 0 && (row < 0 || obi < row));
@@ -277,7 +305,6 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
         const float nm2 = fmaxf(lost, fmaxf(s2, om2));
         const float nm1 = other ? om1 : s1;
         const int nbi = other ? obi : row;
-        const int qi = qw0 + ct * 32 + li;
         if (h != 0 || qi >= nq) continue;
         uint32_t k1 = kNoKey, k2 = kNoKey;
         if (qi < nqv && nbi >= 0) {
@@ -371,12 +398,12 @@ extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_
         hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, t1, view_t, n_t, nt,
                            p.tiles, img);
 #define PH_LAUNCH(QT) hipLaunchKernelGGL(hamming_fp4_dma_kernel<QT>, grid, dim3(256), 0, st, q4, img, p.tiles, view_q, n_q, n_t, \
-                                         nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part)
+                                         nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part, (const uint4*)t1, view_t)
         if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
 #undef PH_LAUNCH
     } else {                                   // no train rows: every query gets "no neighbour"
         hipLaunchKernelGGL(hamming_fp4_dma_kernel<1>, grid, dim3(256), 0, st, q4, (const uint4*)nullptr, 0, view_q, n_q, n_t, nq,
-                           nt, p.splits, p.rows_per_split, idx, d1, d2, part);
+                           nt, p.splits, p.rows_per_split, idx, d1, d2, part, (const uint4*)nullptr, view_t);
     }
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;
