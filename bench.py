@@ -45,8 +45,10 @@ THR_PX = 1.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed steps (200 x 1.8 ms: the first steps of a region fill the three-stream pipeline and the chip's "
+                         "power management takes ~0.1 s to settle; 20 steps read 3-4 %% lower)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--pairs", type=int, default=64, help="pairs per step per GPU (64: the filter kernel runs 12 % faster per pair than at 32 — longer launches, smaller tails)")
     ap.add_argument("--samples", type=int, default=N_SAMPLES, help="5-point minimal samples per pair (10 hypothesis slots each)")
     ap.add_argument("--cpu-pairs", type=int, default=32, help="pairs timed through the CPU oracle (0 = skip)")
