@@ -5,7 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from pose_estimation_amd import matching
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(7)
+only = int(sys.argv[1]) if len(sys.argv) > 1 else 0          # 32768 or 8192: that shape alone (counter passes)
 for n, B in ((32768, 28), (8192, 496)):
+    if only and n != only:
+        continue
     V = 8 if n == 32768 else 32
     tab = torch.randint(0, 256, (V, n, 32), dtype=torch.uint8, generator=g).to(dev)
     pairs = [(i, j) for i in range(V) for j in range(i + 1, V)][:B]

@@ -69,7 +69,10 @@ __device__ __forceinline__ uint4 expand32_fp4(uint32_t w) {
 // ---- fp4 matcher with the train view expanded ONCE per pair (not once per query block: 128 blocks of a 32 768-row
 // view used to repeat the 32-bit -> 32-nibble expansion of every tile) into ready-made LDS tile images that the query
 // blocks stream with LDS-DMA: no staging registers, VALU or LDS writes in the loop (the scheme of match_l2_filter.hip).
-//   image of a staged tile (64 rows): uint4 [sub*256 + r*8 + (c ^ (r & 7))], sub = 0..1, r = 0..31, c = 16-byte chunk;
+//   image of a staged tile (64 rows): uint4 [sub*256 + r*8 + (c ^ ((r >> 1) & 7))], sub = 0..1, r = 0..31, c = 16-byte chunk
+//                                     (a row is 128 bytes = half of the 64 banks: the sixteen lanes of one pass of a ds_read_b128
+//                                     read rows r .. r+15, i.e. eight 256-byte bank lines twice — swizzled with r & 7 two of them met
+//                                     in every bank quad, SQ_LDS_BANK_CONFLICT = 2 cycles per MFMA; with (r >> 1) & 7 none do);
 //                                     rows at or beyond the pair's valid count are all-zero nibbles
 constexpr int kHSub = 2;
 constexpr int kHSR = kMR * kHSub;                       // rows per staged tile
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void hamming_expand_kernel(const uint32_t* __r
         const int id = tid + 256 * u, row = id >> 3, part = id & 7, sub = row >> 5, r = row & 31;
         const bool ok = t0 + row < ntv;
         const uint32_t wd = ok ? T[(size_t)(t0 + row) * 8 + part] : 0u;
-        out[sub * (kMR * 8) + r * 8 + (part ^ (r & 7))] = ok ? expand32_fp4(wd) : make_uint4(0u, 0u, 0u, 0u);
+        out[sub * (kMR * 8) + r * 8 + (part ^ ((r >> 1) & 7))] = ok ? expand32_fp4(wd) : make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
         };
         unsigned aoff[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) aoff[s] = (unsigned)(li * 8 + ((2 * s + h) ^ (li & 7))) * 16u;
+        for (int s = 0; s < 4; ++s) aoff[s] = (unsigned)(li * 8 + ((2 * s + h) ^ ((li >> 1) & 7))) * 16u;
         stage(0, 0);
         if (n_iter > 1) { stage(1, 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
