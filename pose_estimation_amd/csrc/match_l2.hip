@@ -64,13 +64,13 @@ __global__ __launch_bounds__(256) void l2_sqnorm_coalesced_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int r = 8 * i + (lane >> 3), c = lane & 7;
-            if (r0 + r < n_rows) my[r * 8 + (c ^ (r & 7))] = T[(size_t)(r0 + r) * cpr + c0 + c];
+            if (r0 + r < n_rows) my[r * 8 + (c ^ ((r >> 1) & 7))] = T[(size_t)(r0 + r) * cpr + c0 + c];
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the LDS block is this wave's own; a wave's LDS
         __builtin_amdgcn_wave_barrier();                         // operations complete in order
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float4 x = my[lane * 8 + (c ^ (lane & 7))];
+            const float4 x = my[lane * 8 + (c ^ ((lane >> 1) & 7))];   // 128-byte rows: (row >> 1) & 7, not row & 7, keeps a 16-lane pass conflict-free
             acc = ph_fma(x.x, x.x, acc); acc = ph_fma(x.y, x.y, acc);
             acc = ph_fma(x.z, x.z, acc); acc = ph_fma(x.w, x.w, acc);
         }
