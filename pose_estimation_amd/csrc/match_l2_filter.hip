@@ -38,6 +38,9 @@
 #ifndef PH_ABLATE
 #define PH_ABLATE 0
 #endif
+#ifndef PH_F16_DROP
+#define PH_F16_DROP 0        // low mantissa bits of the fp16 MFMA operands left unused (keep_bits below)
+#endif
 #ifndef PH_RR_UNROLL
 #define PH_RR_UNROLL 4
 #endif
@@ -55,7 +58,10 @@ constexpr int kQT = 2;        // 32-query column tiles per wave
 constexpr int kDim = 128;
 constexpr int kCPR = kDim / 8;  // 16-byte fp16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
-constexpr int kCapH = 32;      // list entries per (query, split, lane half)
+#ifndef PH_CAPH
+#define PH_CAPH 32
+#endif
+constexpr int kCapH = PH_CAPH;  // list entries per (query, split, lane half)
 constexpr int kBlocksPerCU = 2;   // blocks per CU the split count of a SMALL batch aims at (3, the residency, times the same: 8 pairs
                                   // 6 % faster, 16 pairs 7 % slower)
 constexpr int kDepth = 2;         // staged tiles copied ahead of the one being worked on (3: same time; 4: slower)
@@ -81,17 +87,28 @@ __device__ __forceinline__ PairScale pair_scale(float Tmax, float Qmax) {
 // 2 e_i in scaled units
 __device__ __forceinline__ float band2_scaled(float qnorm_sq, float Tmax, float Qmax, float s) {
     const float qn = sqrtf(qnorm_sq);
-    const float e = (1.0f / 1024.0f + 1.0f / 8192.0f) * (qn * Tmax + 0.5f * Tmax * Tmax) + (1.0f / 8388608.0f) * Tmax * (qn + Qmax);
+    const float e = ((float)(1 << PH_F16_DROP) / 1024.0f + 1.0f / 8192.0f) * (qn * Tmax + 0.5f * Tmax * Tmax) + (1.0f / 8388608.0f) * Tmax * (qn + Qmax);
     return 2.0f * e * s;
 }
 
+// x rounded (to nearest) to 11 - PH_F16_DROP significant bits, exactly (Veltkamp's splitting); with PH_F16_DROP = 0 the
+// identity: the conversion to fp16 does the rounding.  Fewer significant bits in the MFMA operands mean less switching in
+// the matrix pipes, and the chip, power-limited on this instruction, holds a higher clock (profiles/r2/mfma_bits.txt).
+__device__ __forceinline__ float keep_bits(float x) {
+#if PH_F16_DROP > 0
+    const float c = x * (float)((1 << (13 + PH_F16_DROP)) + 1);
+    return c - (c - x);
+#else
+    return x;
+#endif
+}
 // 8 consecutive f32, scaled by a power of two -> 8 fp16 (round to nearest even)
 __device__ __forceinline__ uint4 to_f16x8(const float4 a, const float4 b, float scale) {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t h[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const _Float16 lo = (_Float16)(x[2 * p] * scale), hi = (_Float16)(x[2 * p + 1] * scale);
+        const _Float16 lo = (_Float16)keep_bits(x[2 * p] * scale), hi = (_Float16)keep_bits(x[2 * p + 1] * scale);
         h[p] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
     }
     return make_uint4(h[0], h[1], h[2], h[3]);
