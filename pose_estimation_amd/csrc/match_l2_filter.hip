@@ -32,18 +32,6 @@
 
 #include "common.hpp"
 #include "match_l2_filter.hpp"
-#ifndef PH_FILTER_LDS_PAD
-#define PH_FILTER_LDS_PAD 0      // uint4 of unused LDS per block: 464 leaves room for two blocks per CU instead of three (experiments)
-#endif
-#ifndef PH_ABLATE
-#define PH_ABLATE 0
-#endif
-#ifndef PH_F16_DROP
-#define PH_F16_DROP 0        // low mantissa bits of the fp16 MFMA operands left unused (keep_bits below)
-#endif
-#ifndef PH_RR_UNROLL
-#define PH_RR_UNROLL 4
-#endif
 
 namespace {
 
@@ -58,10 +46,7 @@ constexpr int kQT = 2;        // 32-query column tiles per wave
 constexpr int kDim = 128;
 constexpr int kCPR = kDim / 8;  // 16-byte fp16 chunks per row
 constexpr int kNS = kDim / 16;  // MFMA k-steps per row
-#ifndef PH_CAPH
-#define PH_CAPH 32
-#endif
-constexpr int kCapH = PH_CAPH;  // list entries per (query, split, lane half)
+constexpr int kCapH = 32;     // list entries per (query, split, lane half)
 constexpr int kBlocksPerCU = 2;   // blocks per CU the split count of a SMALL batch aims at (3, the residency, times the same: 8 pairs
                                   // 6 % faster, 16 pairs 7 % slower)
 constexpr int kDepth = 2;         // staged tiles copied ahead of the one being worked on (3: same time; 4: slower)
@@ -87,28 +72,17 @@ __device__ __forceinline__ PairScale pair_scale(float Tmax, float Qmax) {
 // 2 e_i in scaled units
 __device__ __forceinline__ float band2_scaled(float qnorm_sq, float Tmax, float Qmax, float s) {
     const float qn = sqrtf(qnorm_sq);
-    const float e = ((float)(1 << PH_F16_DROP) / 1024.0f + 1.0f / 8192.0f) * (qn * Tmax + 0.5f * Tmax * Tmax) + (1.0f / 8388608.0f) * Tmax * (qn + Qmax);
+    const float e = (1.0f / 1024.0f + 1.0f / 8192.0f) * (qn * Tmax + 0.5f * Tmax * Tmax) + (1.0f / 8388608.0f) * Tmax * (qn + Qmax);
     return 2.0f * e * s;
 }
 
-// x rounded (to nearest) to 11 - PH_F16_DROP significant bits, exactly (Veltkamp's splitting); with PH_F16_DROP = 0 the
-// identity: the conversion to fp16 does the rounding.  Fewer significant bits in the MFMA operands mean less switching in
-// the matrix pipes, and the chip, power-limited on this instruction, holds a higher clock (profiles/r2/mfma_bits.txt).
-__device__ __forceinline__ float keep_bits(float x) {
-#if PH_F16_DROP > 0
-    const float c = x * (float)((1 << (13 + PH_F16_DROP)) + 1);
-    return c - (c - x);
-#else
-    return x;
-#endif
-}
 // 8 consecutive f32, scaled by a power of two -> 8 fp16 (round to nearest even)
 __device__ __forceinline__ uint4 to_f16x8(const float4 a, const float4 b, float scale) {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     uint32_t h[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const _Float16 lo = (_Float16)keep_bits(x[2 * p] * scale), hi = (_Float16)keep_bits(x[2 * p + 1] * scale);
+        const _Float16 lo = (_Float16)(x[2 * p] * scale), hi = (_Float16)(x[2 * p + 1] * scale);
         h[p] = (uint32_t)__builtin_bit_cast(unsigned short, lo) | ((uint32_t)__builtin_bit_cast(unsigned short, hi) << 16);
     }
     return make_uint4(h[0], h[1], h[2], h[3]);
@@ -170,6 +144,10 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
     if (tid < 2) tqmax[tid * B + b] = sqrtf(fmaxf(fmaxf(red[tid][0], red[tid][1]), fmaxf(red[tid][2], red[tid][3])));
 }
 
+// Finite? — on the bits: this file is built with -fno-honor-nans, under which a floating-point comparison may be compiled
+// into its negated opposite and say anything about a NaN.
+__device__ __forceinline__ bool finite_bits(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
+
 // Train tile image, written once per (pair, staged tile) and streamed by every query block of the pair straight into
 // LDS (global_load_lds: no registers, no VALU, no LDS write instructions in the filter loop).  It is the LDS image:
 //   uint4 [0, kSub*512)          scaled fp16 rows, MFMA tile after MFMA tile; chunk p of row r at r*16 + (p ^ (r & 15))
@@ -178,6 +156,8 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
 //                                LDS pipe is the busiest unit of this kernel — at the MFMA peak a CU has time for one
 //                                ds_read_b128 per MFMA, and a copy of the presets per column tile was 0.5 of that);
 //                                -inf for rows at or beyond the pair's valid count
+// A train row whose squared norm is not finite (a NaN or an overflowing element: outside the contract, posehot.h) is written
+// as a padded row — zeros and a -inf preset: it can never be listed, whatever the compiler makes of comparisons with NaN.
 constexpr int kImgRows = kSub * kTR * kCPR;               // uint4
 constexpr int kImgTail = kSub * kTR / 4;                  // uint4
 constexpr int kImg = kImgRows + kImgTail;                 // uint4 per staged tile image
@@ -195,7 +175,7 @@ __global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restric
 #pragma unroll
     for (int u = 0; u < kImgRows / 256; ++u) {
         const int id = tid + 256 * u, row = id / kCPR, p = id % kCPR;      // row within the staged tile
-        const bool ok = t0 + row < ntv;
+        const bool ok = t0 + row < ntv && finite_bits(tnorm[(size_t)vt * nt + min(t0 + row, nt - 1)]);
         const float4* src = T + (size_t)(t0 + row) * (kDim / 4) + 2 * p;
         const float4 a = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 c = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -203,7 +183,8 @@ __global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restric
     }
     if (tid < kSub * kTR) {
         const int sub = tid / kTR, row = sub * kTR + (tid & (kTR - 1));
-        ((float*)(out + kImgRows))[tid] = (t0 + row < ntv) ? -0.5f * tnorm[(size_t)vt * nt + t0 + row] * sc.s : -INFINITY;
+        const float tn = tnorm[(size_t)vt * nt + min(t0 + row, nt - 1)];
+        ((float*)(out + kImgRows))[tid] = (t0 + row < ntv && finite_bits(tn)) ? -0.5f * tn * sc.s : -INFINITY;
     }
 }
 
@@ -237,7 +218,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
     constexpr int NT = WAVES * 64;
     static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256 && kSub * kTR <= 256, "staging deal");
-    __shared__ uint4 smem[(kDepth + 1) * kImg + PH_FILTER_LDS_PAD];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
+    __shared__ uint4 smem[(kDepth + 1) * kImg];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -271,8 +252,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     uint4 bh[kQT][kNS];
     float thr[kQT], eps2[kQT], a1[kQT], a2[kQT];
     size_t qoff[kQT];
-    unsigned lbase[kQT];                             // byte offset of this lane's private list segment in the pair's lists
-    int nc[kQT];                                     // entries in it
+    unsigned lpos[kQT], lend[kQT];                   // byte offsets in the pair's lists: where this lane's private segment takes its
+                                                     // next entry (it keeps counting beyond the end: overflow), and the segment's end
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct) {
         const int qi = qw0 + ct * 32 + li;
@@ -281,8 +262,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         for (int s = 0; s < kNS; ++s) bh[ct][s] = to_f16x8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], sc.sq);
         const bool live = qi < nqv;
         qoff[ct] = ((size_t)b * nq + min(qi, nq - 1)) * slots + (2 * split + h);
-        lbase[ct] = (unsigned)(((size_t)min(qi, nq - 1) * slots + (2 * split + h)) * kCapH * sizeof(int2));
-        nc[ct] = 0;
+        lpos[ct] = (unsigned)(((size_t)min(qi, nq - 1) * slots + (2 * split + h)) * kCapH * sizeof(int2));
+        lend[ct] = lpos[ct] + (unsigned)(kCapH * sizeof(int2));
         eps2[ct] = band2_scaled(QN[min(qi, nq - 1)], Tm, Qm, sc.s);
         thr[ct] = live ? -3.0e38f : INFINITY;           // finite floor: the -inf score of a padded row never reaches it;
                                                          // a dead lane never has a candidate
@@ -307,19 +288,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     const unsigned wave_s = __builtin_amdgcn_readfirstlane(wave);
     const unsigned voff = (unsigned)tid * 16u;
     auto stage = [&](int tile, int buf) {
-#if PH_ABLATE & 32
-        const char* src = (const char*)(IMG + (size_t)(tile & 1) * kImg);
-#else
         const char* src = (const char*)(IMG + (size_t)tile * kImg);
-#endif
         const unsigned dst = lds_addr(smem) + (unsigned)buf * (kImg * 16u) + wave_s * 1024u;
 #pragma unroll
-        for (int u = 0; u < kImgRows / 256; ++u) {
-#if PH_ABLATE & 16
-            if (u >= 2) break;
-#endif
-            glds16s(src + 4096 * u, voff, dst + 4096u * u);
-        }
+        for (int u = 0; u < kImgRows / 256; ++u) glds16s(src + 4096 * u, voff, dst + 4096u * u);
         // tail: lane l of wave w copies chunk w * (kImgTail / 4) + l; the lane offset register carries w * 1024 too much
         if (lane < kImgTail / 4)
             glds16s(src + kImgRows * 16 + (long)wave_s * (kImgTail / 4 * 16) - (long)wave_s * 1024, voff,
@@ -358,13 +330,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         constexpr unsigned base = decltype(bufc)::value * (kImg * 16u) + decltype(subc)::value * (kTR * kCPR * 16u);
         constexpr unsigned pbase = decltype(bufc)::value * (kImg * 16u) + kImgRows * 16u + decltype(subc)::value * (kTR * 4u);
         const char* sm = (const char*)smem;
-        auto frag = [&](int s) {
-#if PH_ABLATE & 2
-            return bh[0][s ^ 1];
-#else
-            return *(const uint4*)(sm + (aoff[s] + base));
-#endif
-        };
+        auto frag = [&](int s) { return *(const uint4*)(sm + (aoff[s] + base)); };
         // issue order pinned by hand (scheduling barriers): presets and two fragments up front, then one fragment read
         // per k-step, two steps ahead of the MFMAs that consume it
         uint4 af[kNS];
@@ -422,16 +388,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     // skip branch, and those branches, not the instructions, were what the slow path cost.
     auto hit = [&](float v, int jrow, int ct) {
         const bool c = v >= thr[ct];
-        const unsigned off = (c && nc[ct] < kCapH) ? lbase[ct] + 8u * (unsigned)nc[ct] : 0xffffffffu;
+        const unsigned off = (c && lpos[ct] < lend[ct]) ? lpos[ct] : 0xffffffffu;
         const i32x2 d = {jrow, __float_as_int(v)};
         __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, off, 0, 0);
-        nc[ct] += c ? 1 : 0;
+        lpos[ct] += c ? 8u : 0u;
     };
     auto any_ge = [&](float m, int ct) { return __builtin_amdgcn_ballot_w64(m >= thr[ct]) != 0ull; };
-    auto filter = [&](const f32x16& acc, int ct, int t0) {
+    auto filter = [&](const f32x16& acc, int ct, int t0, bool first_visit) {
         float m4[4];
         const float m = tile_max(acc, m4);
-        track(m, ct);
+        if (first_visit) track(m, ct);               // wave-uniform; a row must not enter (a1, a2) twice
         if (!any_ge(m, ct)) return;
         const int t0s = __builtin_amdgcn_readfirstlane(t0);
 #pragma unroll
@@ -439,11 +405,12 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
             if (!any_ge(m4[g4], ct)) continue;
             // one append per entered group: the lane's largest of the four (a lane with a hit has, as a rule, one)
             const float a = acc[4 * g4], b = acc[4 * g4 + 1], c = acc[4 * g4 + 2], d = acc[4 * g4 + 3], mg = m4[g4];
-            int k = (d == mg) ? 3 : 0;
-            k = (c == mg) ? 2 : k; k = (b == mg) ? 1 : k; k = (a == mg) ? 0 : k;
+            int k = (c == mg) ? 2 : 3;               // mg is one of the four
+            k = (b == mg) ? 1 : k; k = (a == mg) ? 0 : k;
             hit(mg, t0s + 8 * g4 + k, ct);
             // a second row of the same four reaching the bound (second-largest of the four): the other three one by one
-            const float second = vmax(fminf(vmax(a, b), vmax(c, d)), vmax(fminf(a, b), fminf(c, d)));
+            // second-largest of four = median of (second-largest of three, largest of three, the fourth)
+            const float second = __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(a, b, c), vmax(vmax(a, b), c), d);
             if (any_ge(second, ct)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hit(r == k ? -INFINITY : acc[4 * g4 + r], t0s + 8 * g4 + r, ct);
@@ -463,11 +430,16 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         static_assert(kDepth <= 4, "one case per possible count below");
         if (ahead >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * kGlds) : "memory");
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * kGlds) : "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PH_ABLATE & 16) ? kGlds - 2 : kGlds) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kGlds) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    const int n_iter = n_prime + n_tiles;
-    auto tile_of = [&](int it) { return t_begin / kSR + (it < n_prime ? it : it - n_prime); };
+    // Order of the staged tiles: all n_tiles once — the first n_prime of them only tracked (priming: the bound is still
+    // useless), the others tracked and filtered — and then the primed ones once more, filtered under what is by then the
+    // FINAL bound: a primed row is listed only if it can be one of the exact top-2 (seen again FIRST, as before round 3, the
+    // primed top-2 of every lane half re-entered the lists: 2 of ~10 listed rows per query).  (a1, a2) run over
+    // the first visits only, so they always describe distinct rows.
+    const int n_iter = n_tiles + n_prime;
+    auto tile_of = [&](int it) { return t_begin / kSR + (it < n_tiles ? it : it - n_tiles); };
 #pragma unroll
     for (int d = 0; d < kDepth; ++d)
         if (d < n_iter) stage(tile_of(d), d);
@@ -477,47 +449,25 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         constexpr int BUF = decltype(bufc)::value, NXT = (BUF + kDepth) % (kDepth + 1);
         const bool priming = it < n_prime;
         const int t0 = tile_of(it) * kSR;
-#if !(PH_ABLATE & 8)
         __builtin_amdgcn_s_barrier();
-#endif
         asm volatile("" ::: "memory");
-#if !(PH_ABLATE & 4)
         if (it + kDepth < n_iter) stage(tile_of(it + kDepth), NXT);
-#endif
         auto work = [&](auto subc) {
             constexpr int sub = decltype(subc)::value;
             f32x16 acc[kQT];
             tile_scores(bufc, subc, acc);
             // tile it+1 landed (waited for before the first list store of this iteration is issued: the counter retires in order)
             if (sub == 0) wait_ahead(min(kDepth, n_iter - 1 - it) - 1 < 0 ? 0 : min(kDepth, n_iter - 1 - it) - 1);
-#if PH_ABLATE & 1
-            if (true) {
-#pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) asm volatile("" :: "v"(acc[ct]));
-            } else
-#endif
             if (priming) {
 #pragma unroll
                 for (int ct = 0; ct < kQT; ++ct) prime(acc[ct], ct);
             } else {
 #pragma unroll
-                for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0 + sub * kTR);
+                for (int ct = 0; ct < kQT; ++ct) filter(acc[ct], ct, t0 + sub * kTR, it < n_tiles);
             }
         };
         work(std::integral_constant<int, 0>{});
         work(std::integral_constant<int, 1>{});
-        if (it + 1 == n_prime) {
-#pragma unroll
-            for (int ct = 0; ct < kQT; ++ct) {
-                // second-largest of the union of the two halves' top-2, then restart the tracking: the primed
-                // rows are seen again by the filtering pass
-                float l1, h1, l2, h2;
-                both_halves(a1[ct], l1, h1); both_halves(a2[ct], l2, h2);
-                const float second = fmaxf(fminf(l1, h1), fmaxf(l2, h2));
-                thr[ct] = fmaxf(thr[ct], second - eps2[ct]);
-                a1[ct] = -INFINITY; a2[ct] = -INFINITY;
-            }
-        }
     };
     for (int it = 0; it < n_iter; it += kDepth + 1) {
         iteration(std::integral_constant<int, 0>{}, it);
@@ -526,7 +476,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     }
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct)
-        if (qw0 + ct * 32 + li < nqv) cnt[qoff[ct]] = nc[ct];
+        if (qw0 + ct * 32 + li < nqv) cnt[qoff[ct]] = kCapH - (int)(lend[ct] - lpos[ct]) / 8;   // signed: lpos may have run past the end
 }
 
 // exact contract chain: s = fma chain over k in the order 8c + {0,4,1,5,2,6,3,7}, started at -|t|^2/2
@@ -555,22 +505,15 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
 // the wave's instructions serves: with the rows staged through LDS (the previous version: 8 rows per pass, 4 KB of LDS per
 // wave for them and 4 KB for the query rows) a wave issued three passes for its ~20 rows and a quarter of all issue
 // slots of the kernel were chain instructions with 8 of 64 lanes on; now it is one pass for ~40 rows.
-#ifndef PH_RL
-#define PH_RL 4
-#endif
-constexpr int kRL = PH_RL;
+constexpr int kRL = 4;
+constexpr int kRRUnroll = 4;           // chain unroll of the re-rank pass (8 spills the row loads of a pass)
 constexpr int kRQ = 64 / kRL;          // queries per wave
 constexpr int kRQueue = 128;           // queue length that triggers a flush (a typical wave queues about 20 rows in all)
-#ifndef PH_RR_QLDS
-#define PH_RR_QLDS 1
-#endif
 struct RerankLds {
     int qj[kRQueue + 64];              // wave queue of candidates: train row ...
     int qq[kRQueue + 64];              // ... and query (0 .. kRQ-1) of the wave
     float rs[64];                      // exact scores of one pass of 64 queued rows
-#if PH_RR_QLDS
     float4 qrow[kRQ * 32];             // the wave's query rows: query d's chunk c at d*32 + (c ^ d)
-#endif
 };
 // FUSE = the ratio test in the same kernel (ph_match_l2_ratio): keep = what ph_match_l2_top2 followed by ph_ratio_filter_l2
 // give, bit for bit, idx = their idx where keep is set and PH_NO_INDEX where it is not, but a query whose answer already
@@ -712,17 +655,15 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     };
 
     // (3) + (4) for the first n queued rows
-    [[maybe_unused]] const float4* Qw = (const float4*)(dq + ((size_t)vq * nq + min(bq * QPB + wave * kRQ, nq - 1)) * kDim);   // row of the wave's first query
     auto flush = [&](int n) {
         for (int base = 0; base < n; base += 64) {
             const int k = min(64, n - base);
             if (lane < k) {
                 const int j = L.qj[base + lane], qd = L.qq[base + lane];
-#if PH_RR_QLDS
                 const float4* t = Tt + (size_t)j * (kDim / 4);
                 const float4* qr = &L.qrow[qd * 32];
                 float acc = -0.5f * TN[j];
-#pragma unroll PH_RR_UNROLL
+#pragma unroll kRRUnroll
                 for (int c = 0; c < kDim / 8; ++c) {
                     const float4 q0 = qr[(2 * c) ^ qd], q1 = qr[(2 * c + 1) ^ qd], t0 = t[2 * c], t1 = t[2 * c + 1];
                     acc = ph_fma(t0.x, q0.x, acc); acc = ph_fma(t1.x, q1.x, acc);
@@ -731,9 +672,6 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
                     acc = ph_fma(t0.w, q0.w, acc); acc = ph_fma(t1.w, q1.w, acc);
                 }
                 L.rs[lane] = acc;
-#else
-                L.rs[lane] = exact_score<PH_RR_UNROLL>(Qw + (size_t)qd * (kDim / 4), Tt + (size_t)j * (kDim / 4), TN[j]);
-#endif
             }
             wave_sync();
             for (int r = sl; r < k; r += kRL)
@@ -764,7 +702,6 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         }
     };
     const bool use = live && !overflow && !decided;
-#if PH_RR_QLDS
     // the query rows of the queries that need exact scores -> LDS (16 B per lane and instruction, the four lanes of a query
     // side by side): the chains of a pass would otherwise ask the L1 for the same query line once per lane and chunk.
     // (Issued here, after the lists were read: a decided query of the fused kernel never touches its 512-byte row.)
@@ -772,7 +709,6 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
 #pragma unroll
         for (int c = sl; c < 32; c += kRL) L.qrow[qid * 32 + (c ^ qid)] = q[c];
     }
-#endif
     auto from_memory = [&](int slot, int pass) {
         int j = -1;
         if (use) {
