@@ -131,12 +131,23 @@ def make_batch(pairs, rank, dev):
                 host=dict(desc_q=d1, desc_t=d2, kp_q=k1, kp_t=k2))
 
 
+def opencv_note():
+    """the reference's CPU path is OpenCV; time it if it can be imported, say so if not."""
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        return "OpenCV unavailable (import cv2: ModuleNotFoundError) - the reference's own CPU path cannot be timed on this box"
+    return "OpenCV importable: " + cv2.__version__ + " (not timed: bench.py's CPU leg is the oracle port)"
+
+
 def cpu_baseline(batch, n_pairs, threads, E_dev, real_models):
     """The CPU oracle ('port') over the same stages on a bounded sample of the same workload, and — beside it, as a
     second stated figure — the matcher alone as NumPy/OpenBLAS sgemm + top-2 (what a SIMD BFMatcher roughly costs).
 
-    Hypothesis generation is NOT part of the CPU leg (the oracle's 5-point solver is NumPy and would
-    dominate it): the CPU scores the hypotheses the GPU generated, which only flatters the CPU."""
+    Hypothesis generation and the pose refinement are NOT part of the CPU leg (the oracle's 5-point solver and LM are
+    NumPy and would dominate it): the CPU scores, exhaustively, the live models the GPU generated — the same set the GPU
+    scores with bail-out.  OpenCV, the reference's own CPU path, is not installed on either box, so the
+    `opencv` key says "unavailable" unless `import cv2` succeeds."""
     import numpy as np
     from oracle import oracle as orc
     from pose_estimation_amd import geometry, synthetic
@@ -153,10 +164,11 @@ def cpu_baseline(batch, n_pairs, threads, E_dev, real_models):
         m = orc.compact_matches(idx, keep, h["kp_q"][p], h["kp_t"][p])
         n = m["n_match"]
         pts = [m[k][:n] for k in ("x1", "y1", "x2", "y2")]
-        cnt = orc.score_essential(h["E"][p], *pts, thr_sq)
+        live = h["E"][p][np.any(h["E"][p] != 0.0, axis=1)]          # the models the GPU path scores (ph_compact_models)
+        cnt = orc.score_essential(live, *pts, thr_sq)
         bi, _ = orc.select_best(cnt)
-        mask = orc.inlier_mask_essential(h["E"][p][bi], *pts, thr_sq, N_FEAT)
-        P1, P2, _, _ = geometry.candidate_projections(h["E"][p][bi].reshape(1, 3, 3))
+        mask = orc.inlier_mask_essential(live[bi], *pts, thr_sq, N_FEAT)
+        P1, P2, _, _ = geometry.candidate_projections(live[bi].reshape(1, 3, 3))
         for c in range(4):
             orc.triangulate(P1[0, c], P2[0, c], *pts, mask)
     dt = time.perf_counter() - t0
@@ -173,8 +185,9 @@ def cpu_baseline(batch, n_pairs, threads, E_dev, real_models):
     rest = (dt - t_match) / n_pairs
     return {"value": n_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
             "sample": f"{n_pairs} pair(s) of the same workload through oracle/posehot_oracle.c (OpenMP, {threads} threads), "
-                      f"exhaustive scoring of the {E_dev.shape[1]} hypothesis slots the GPU generated (~{real_models:.0f} real models), "
-                      f"hypothesis generation excluded, {dt:.1f} s",
+                      f"exhaustive scoring of the ~{real_models:.0f} live models per pair the GPU generated (empty solver slots skipped, "
+                      f"as on the GPU), hypothesis generation and refinement excluded, {dt:.1f} s",
+            "opencv": opencv_note(),
             "blas_matcher": {"value": 1.0 / (blas_dt + rest), "unit": "pairs/s",
                              "note": "same CPU leg with the matcher replaced by NumPy/OpenBLAS sgemm q@t.T + argpartition top-2 "
                                      f"({blas_dt * 1e3:.0f} ms per pair over {nb} pairs; NOT bit-exact with the contract's fma chain), "

@@ -279,7 +279,11 @@ int ph_gather_models(const float* models, const int32_t* sel, int B, int H, int 
  * order, the tail zero-filled (must not alias `models`); slot [B][H]: the slot a compact position came from, -1 in the tail;
  * n_live [B].  Scoring the compact block costs what its live models cost — a wave of eight empty slots leaves at once — and
  * ph_select_best of its counts, mapped back with ph_lookup_index (out[b] = table[b][sel[b]], -1 outside [0, H)), is the
- * winner of the slot layout, ties included (the order is kept).  No reference counterpart (glue of north_star's RANSAC). */
+ * winner of the slot layout, ties included (the order is kept) — as long as some model has an inlier.  When the best count
+ * is 0 the two layouts differ: the slot layout's argmax is slot 0 (possibly an empty slot), the compact layout's is the first
+ * LIVE slot; and an item without any live model (fewer matches than a minimal sample: every slot empty) maps to -1.  Every
+ * consumer of such an index clamps it, the pose-table status of such an item is 0 (inliers < min_inliers), nothing faults.
+ * No reference counterpart (glue of north_star's RANSAC). */
 int ph_compact_models(const float* models, int B, int H, int stride, float* out, int32_t* slot, int32_t* n_live,
                       void* stream);
 int ph_lookup_index(const int32_t* table, const int32_t* sel, int B, int H, int32_t* out, void* stream);

@@ -13,12 +13,14 @@ Mirrors (reference file:line):
 Error convention as in the reference: sentinel returns (None, None, n), never exceptions, for
 "no markers / too few points / solver failed" (main.py:91-107).
 
-Where the arithmetic runs: projection and reprojection-error statistics are batched float64
-HIP kernels (csrc/board.hip) behind the C ABI.  The pose solve follows
-cv2.solvePnP(SOLVEPNP_ITERATIVE) on coplanar points as documented — homography-based initial
-pose (host, one 9x9 SVD per image), then Levenberg-Marquardt on the distorted reprojection
-error, which runs batched on the GPU (ph_refine_pose_lm, float64, one block per image); cv2 is
-not installed here, so this step is "parity unpinned" against OpenCV's exact iteration schedule.
+Where the arithmetic runs: everything is a batched float64 HIP kernel (csrc/board.hip) behind the C ABI.  The pose
+solve follows cv2.solvePnP(SOLVEPNP_ITERATIVE) on coplanar points as documented: the homography-based initial pose
+(`ph_initial_board_pose`, one block per image: normalised DLT normal matrix, Jacobi eigenvector, Newton polar factor),
+then Levenberg-Marquardt on the distorted reprojection error (`ph_refine_pose_lm`, one block per image) — two launches
+for all images of a folder, no host linear algebra.  Projection, reprojection-error statistics and the camera
+inversion / quaternion epilogue (`ph_camera_from_pose`) are one launch each.  cv2 is not installed here, so the solve is
+"parity unpinned" against OpenCV's exact iteration schedule.  The NumPy twins kept in this file (`rodrigues`,
+`_homography_pose`, the single-pose `get_camera_position_and_orientation`) serve callers without a batch and the CPU tests.
 """
 from __future__ import annotations
 
@@ -235,23 +237,17 @@ def _quat_xyzw(Rm):
 
 
 def get_camera_position_and_orientation(rvec, tvec):
-    """main.py:112-143 — (position, forward, up, R_cam_to_world, quaternion [w,x,y,z]).
+    """main.py:112-143 — (position, forward, up, R_cam_to_world, quaternion [w,x,y,z]) of ONE pose, on the host.
 
-    Forward is +Z of the camera (the code, main.py:132, not its comment); up is -Y (main.py:135).
-    """
-    R_board_to_cam = rodrigues(rvec)
-    tvec = np.asarray(tvec, np.float64).reshape(3, 1)
-    camera_position = -R_board_to_cam.T @ tvec
-    R_cam_to_world = R_board_to_cam.T
-    camera_forward = R_cam_to_world @ np.array([[0], [0], [1]])
-    camera_up = R_cam_to_world @ np.array([[0], [-1], [0]])
-    try:  # the reference's own dependency; identical output, kept so the convention stays pinned to SciPy
-        from scipy.spatial.transform import Rotation as _Rot
-        quaternion = _Rot.from_matrix(R_cam_to_world).as_quat()
-    except ImportError:
-        quaternion = _quat_xyzw(R_cam_to_world)
-    quaternion_wxyz = np.array([quaternion[3], quaternion[0], quaternion[1], quaternion[2]])
-    return camera_position.flatten(), camera_forward.flatten(), camera_up.flatten(), R_cam_to_world, quaternion_wxyz
+    The pose maps board to camera coordinates, x_cam = R x_board + t, so the camera sits at -R't and its axes, seen from
+    the board, are the columns of R': forward is the camera's +Z (what the reference's code does, main.py:132, not what its
+    comment says), up its -Y (main.py:135).  The quaternion is SciPy's ``Rotation.from_matrix(R').as_quat()`` — sign included,
+    pinned by tests/golden/quaternions.json — reordered to w first (main.py:138-141).  Batches go through
+    `camera_from_pose_batched` (one `ph_camera_from_pose` launch); the two agree to 1e-14 (tests/test_gpu_pnp.py)."""
+    Rcw = rodrigues(rvec).T
+    centre = -(Rcw @ np.asarray(tvec, np.float64).reshape(3))
+    x, y, z, w = _quat_xyzw(Rcw)
+    return centre, Rcw[:, 2].copy(), -Rcw[:, 1], Rcw, np.array([w, x, y, z])
 
 
 def camera_from_pose_batched(pose):

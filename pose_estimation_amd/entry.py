@@ -77,7 +77,17 @@ def process_detections(dets, board, camera_matrix, dist_coeffs, verbose=True):
     results = []
     # all images' poses in one Levenberg-Marquardt launch; the loop below only formats
     poses = bd.estimate_board_poses([(d["corners"], d["ids"]) for d in dets], board, camera_matrix, dist_coeffs)
-    for d, (rvec, tvec, num_markers) in zip(dets, poses):
+    # ... and all camera inversions + quaternions in one ph_camera_from_pose launch (main.py:112-143, batched)
+    solved = [k for k, (rvec, _, _) in enumerate(poses) if rvec is not None]
+    cams = {}
+    if solved:
+        rt = np.stack([np.concatenate([np.asarray(poses[k][0], np.float64).reshape(3),
+                                       np.asarray(poses[k][1], np.float64).reshape(3)]) for k in solved])
+        cam = {name: v.cpu().numpy() for name, v in
+               bd.camera_from_pose_batched(torch.from_numpy(rt).to(torch.device("cuda", torch.cuda.current_device()))).items()}
+        cams = {k: tuple(cam[name][i] for name in ("position", "forward", "up", "R_cam_to_world", "quaternion"))
+                for i, k in enumerate(solved)}
+    for k, (d, (rvec, tvec, num_markers)) in enumerate(zip(dets, poses)):
         filename, corners, ids = d["filename"], d["corners"], d["ids"]
         if verbose:
             print(f"\n🔍 Processing: {filename}")
@@ -91,7 +101,7 @@ def process_detections(dets, board, camera_matrix, dist_coeffs, verbose=True):
             if verbose:
                 print("  ⚠️ Could not estimate pose")
             continue
-        cam_pos, cam_forward, cam_up, R_cam, quaternion = bd.get_camera_position_and_orientation(rvec, tvec)
+        cam_pos, cam_forward, cam_up, R_cam, quaternion = cams[k]
         if verbose:
             print(f"  ✓ Camera position: [{cam_pos[0]:.3f}, {cam_pos[1]:.3f}, {cam_pos[2]:.3f}] m")
             print(f"  ✓ Quaternion (w,x,y,z): [{quaternion[0]:.4f}, {quaternion[1]:.4f}, {quaternion[2]:.4f}, {quaternion[3]:.4f}]")

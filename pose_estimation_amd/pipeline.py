@@ -128,7 +128,12 @@ def relative_pose_back(f: Front):
     out = dict(table=table, E_hyp=f.E_hyp, n_match=f.n_match, best_idx=f.best_idx, best_count=f.best_count,
                mask=f.mask, front=front, win=win, **f.extra)
     if f.want_points:
-        out["xyz"] = xyz[torch.arange(B, device=dev), win.long()]
+        if f.opts.get("refine", False):
+            # the points of the REFINED pose (the table's R | t), over the winner's inlier mask
+            P2r = torch.cat([table[:, 0:9].reshape(B, 3, 3), table[:, 9:12].reshape(B, 3, 1)], dim=2).reshape(B, 1, 12).contiguous()
+            out["xyz"] = triangulation.triangulate(P1d[:, :1].contiguous(), P2r, *f.pts, n_valid=f.n_match, mask=f.mask)[0][:, 0]
+        else:
+            out["xyz"] = xyz[torch.arange(B, device=dev), win.long()]
         out["pts"] = f.pts
     return out
 
@@ -136,7 +141,12 @@ def relative_pose_back(f: Front):
 def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
                         n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False, refine=True):
     """front + back for one batch of B pairs.  Returns dict(table [B,16] device f32, n_match, best_idx,
-    best_count, mask, E_hyp, front, win and, with want_points, xyz / pts)."""
+    best_count, mask, E_hyp, front, win and, with want_points, xyz / pts).
+
+    With refine=True the table's R | t are the LM-refined pose; best_idx, best_count (table column 12), mask, front and
+    win still describe the winning minimal-sample hypothesis the refinement started from (its RANSAC support), and xyz
+    are the points of the refined pose over that hypothesis' inlier mask.  best_idx is -1 for a pair without a live
+    hypothesis (fewer than 5 matches; status 0)."""
     return relative_pose_back(relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio,
                                                   want_points, n_samples, seed, decompose, item_key, want_counts,
                                                   refine))

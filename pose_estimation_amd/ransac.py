@@ -149,7 +149,10 @@ def refine_relative_pose(x1, y1, x2, y2, pose_rt, trunc_sq, n_valid=None, mask=N
     lib = L.load()
     x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
     B, N = x1.shape
-    pose_rt = L.dev(pose_rt, torch.float32, "pose_rt")
+    # the in-place operand is checked on the CALLER's tensor (L.dev would hand back a contiguous copy of a strided one, and
+    # the refinement would silently land in the copy)
+    if not isinstance(pose_rt, torch.Tensor) or not pose_rt.is_cuda or pose_rt.dtype != torch.float32:
+        raise L.PosehotError("pose_rt must be a float32 tensor on the GPU (there is no CPU path)")
     if pose_rt.dim() != 2 or pose_rt.shape[0] != B or pose_rt.shape[1] < 12:
         raise ValueError("pose_rt must be [B, >= 12] float32")
     if not pose_rt.is_contiguous():

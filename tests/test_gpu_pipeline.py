@@ -128,3 +128,35 @@ def test_device_decomposition_equals_svd_candidates(device):
         assert np.array_equal(P2[b, 0, :, :3], P2[b, 1, :, :3]) and np.array_equal(P2[b, 0, :, 3], -P2[b, 1, :, 3])
         assert np.array_equal(P2[b, 2, :, :3], P2[b, 3, :, :3]) and not np.allclose(P2[b, 0, :, :3], P2[b, 2, :, :3])
     assert np.array_equal(P2[B - 1], np.broadcast_to(eye, (4, 3, 4)).astype(np.float32))
+
+
+def test_pair_without_a_live_hypothesis_is_flagged_not_faulted(device):
+    """A pair with fewer matches than a minimal sample (here: 3 valid queries) has no live model: every solver slot is
+    empty, the compact winner maps to slot -1 (posehot.h, ph_compact_models), every consumer clamps it, the row's status
+    is 0 — and the healthy pair of the same batch is the row it is on its own."""
+    n, S, seed = 2048, 64, 99
+    scs = [synthetic.two_view_pair(n=n, seed=300 + b) for b in range(2)]
+    dq = _t(np.stack([s["desc1"] for s in scs]), device); dt = _t(np.stack([s["desc2"] for s in scs]), device)
+    kq = _t(np.stack([s["kp1"] for s in scs]), device); kt = _t(np.stack([s["kp2"] for s in scs]), device)
+    thr_sq = float(np.float32((1.0 / synthetic.FX) ** 2))
+    key = _t(np.array([7, 8], np.int32), device)
+    for fused in (False, True):
+        n_q = _t(np.array([n, 3], np.int32), device)
+        if fused:
+            match = lambda: (*matching.match_l2_ratio(dq, dt, 0.75, n_q=n_q), "l2_keep")
+        else:
+            match = lambda: (*matching.match_l2(dq, dt, n_q=n_q), "l2")
+        out = pipeline.relative_pose_batch(match, kq, kt, None, None, None, thr_sq, n_samples=S, seed=seed, item_key=key,
+                                           want_points=True, want_counts=True)
+        torch.cuda.synchronize()
+        tab = out["table"].cpu().numpy()
+        assert int(out["n_match"][1]) <= 3 and int(out["n_solutions"][1].sum()) == 0
+        assert tab[1, 15] == pipeline.STATUS_DEGENERATE and tab[1, 12] == 0
+        assert int(out["best_idx"][1]) in (-1, 0) and np.isfinite(tab[1, :12]).all()
+        # the healthy pair does not notice its neighbour
+        alone = pipeline.relative_pose_batch(
+            (lambda: (*matching.match_l2_ratio(dq[:1], dt[:1], 0.75), "l2_keep")) if fused else
+            (lambda: (*matching.match_l2(dq[:1], dt[:1]), "l2")),
+            kq[:1], kt[:1], None, None, None, thr_sq, n_samples=S, seed=seed, item_key=key[:1])
+        assert tab[0, 15] == pipeline.STATUS_OK
+        assert np.array_equal(tab[0].view(np.uint32), alone["table"].cpu().numpy()[0].view(np.uint32))
