@@ -19,3 +19,16 @@ static inline bool ph_aligned(const void* p, size_t a) { return (reinterpret_cas
 
 static inline int ph_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t ph_round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// Zero-fill of n 32-bit words as a KERNEL, never hipMemsetAsync: under stream capture (a caller's hipGraph, plan.py)
+// the memset nodes of this ROCm did not take effect on replay — counters kept the previous replay's contents
+// (benchmarks/dbg/graph_stage.py) — while kernel nodes replay as they were launched.
+static __global__ __launch_bounds__(256) void ph_zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline void ph_zero_words(void* p, size_t n_words, hipStream_t st) {
+    if (n_words == 0) return;
+    size_t blocks = (n_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ph_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n_words);
+}

@@ -263,13 +263,11 @@ int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int
     hipStream_t st = (hipStream_t)stream;
     const ScorePlan p = plan_score(B, H, N > 0 ? N : 1);
     if (p.psplits > 1 || N == 0) {
-        if (hipMemsetAsync(count, 0, sizeof(int32_t) * (size_t)B * H, st) != hipSuccess) return PH_ERR_LAUNCH;
+        ph_zero_words(count, (size_t)B * H, st);
         if (N == 0) return PH_OK;
     }
     const dim3 grid(ph_ceil_div(H, 4 * kHPW), p.psplits, B);
-    if (best_lb) {
-        if (hipMemsetAsync(best_lb, 0, sizeof(int32_t) * (size_t)B * PH_BAILOUT_SLOTS, st) != hipSuccess) return PH_ERR_LAUNCH;
-    }
+    if (best_lb) ph_zero_words(best_lb, (size_t)B * PH_BAILOUT_SLOTS, st);
     if (best_lb && p.psplits == 1) {
         // Seed launch: the first sixteenth of the hypotheses is scored first (with bail-out among themselves) and leaves
         // its best count in every counter, so the main launch knows a real final count from its first chunk on — all

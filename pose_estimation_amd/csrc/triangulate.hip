@@ -380,7 +380,7 @@ extern "C" int ph_triangulate(const float* P1, const float* P2, const float* x1,
     if (B > 65535 || C > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || C == 0) return PH_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (front && hipMemsetAsync(front, 0, sizeof(int32_t) * (size_t)B * C, st) != hipSuccess) return PH_ERR_LAUNCH;
+    if (front) ph_zero_words(front, (size_t)B * C, st);
     if (N == 0) return PH_OK;
     if (!P1 || !P2 || !x1 || !y1 || !x2 || !y2 || (!XYZ && !front)) return PH_ERR_INVALID_ARG;
     hipLaunchKernelGGL(triangulate_kernel, dim3(ph_ceil_div(N, 256), C, B), dim3(256), 0, st, P1, P2, x1, y1, x2, y2,

@@ -49,7 +49,7 @@ class Front:
 
 def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
                         n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False,
-                        refine=True) -> Front:
+                        refine=True, noalloc=False) -> Front:
     """Everything up to the inlier mask, plus (decompose="host") an asynchronous copy of the winning E of every pair.
 
     match: callable returning (idx, d1, d2, kind) with kind "l2" or "hamming",
@@ -63,6 +63,8 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
            into ``Front.extra["n_solutions"]``).
     item_key: per-pair Philox keys (int tensor [B], e.g. global pair ids) so that a pair draws the same minimal
            samples in whatever batch slot, chunk or rank it is processed; None = position in the batch.
+    noalloc: the 5-point solver keeps its records in the library's static scratch (``ph_solve_essential_5pt_noalloc``:
+           at most 8192 samples per batch, one batch at a time per GPU) — for callers under graph capture (plan.py).
     """
     r = match()
     if r[-1] == "l2_keep":
@@ -78,9 +80,9 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     if E_hyp is None:
         samples = ransac.sample_minimal(seed, m["n_match"], pts[0].shape[1], n_samples, item_key=item_key)
         if want_counts:
-            E_hyp, extra["n_solutions"] = ransac.solve_essential_5pt(*pts, samples, want_counts=True)
+            E_hyp, extra["n_solutions"] = ransac.solve_essential_5pt(*pts, samples, want_counts=True, noalloc=noalloc)
         else:
-            E_hyp = ransac.solve_essential_5pt(*pts, samples)
+            E_hyp = ransac.solve_essential_5pt(*pts, samples, noalloc=noalloc)
     if generated:
         # about half of the solver's slots are empty: score the live models packed together (a wave of eight empty
         # slots leaves at once), then map the winner's compact position back to its slot — same winner, ties included
@@ -139,7 +141,8 @@ def relative_pose_back(f: Front):
 
 
 def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=0.75, want_points=False,
-                        n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False, refine=True):
+                        n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False, refine=True,
+                        noalloc=False):
     """front + back for one batch of B pairs.  Returns dict(table [B,16] device f32, n_match, best_idx,
     best_count, mask, E_hyp, front, win and, with want_points, xyz / pts).
 
@@ -149,7 +152,7 @@ def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     hypothesis (fewer than 5 matches; status 0)."""
     return relative_pose_back(relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio,
                                                   want_points, n_samples, seed, decompose, item_key, want_counts,
-                                                  refine))
+                                                  refine, noalloc))
 
 
 def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096, seed=0, refine=True, max_iters=20,

@@ -45,9 +45,15 @@ def sample_minimal(seed, n_valid, N, n_samples, m=5, item_key=None):
     return out
 
 
-def solve_essential_5pt(x1, y1, x2, y2, samples, want_counts=False):
+NOALLOC_MAX_SAMPLES = 8192   # PH_NOALLOC_MAX_SAMPLES (posehot.h)
+
+
+def solve_essential_5pt(x1, y1, x2, y2, samples, want_counts=False, noalloc=False):
     """Nister 5-point solver on the device.  samples int32 ``[B, S, 5]`` -> E ``[B, 10*S, 9]`` float32
-    (10 slots per sample, slot = root index, non-real roots give all-zero slots) and optionally the per-sample solution counts ``[B, S]``."""
+    (10 slots per sample, slot = root index, non-real roots give all-zero slots) and optionally the per-sample solution counts ``[B, S]``.
+
+    noalloc=True: ``ph_solve_essential_5pt_noalloc`` — the polynomial records live in the library's static device scratch
+    instead of a workspace tensor (B * S <= 8192; calls overlapping on one GPU race on it); same outputs, bit for bit."""
     lib = L.load()
     x1, y1, x2, y2 = _pts((x1, y1, x2, y2), ("x1", "y1", "x2", "y2"))
     B, N = x1.shape
@@ -57,6 +63,10 @@ def solve_essential_5pt(x1, y1, x2, y2, samples, want_counts=False):
     S = samples.shape[1]
     E = torch.empty((B, 10 * S, 9), dtype=torch.float32, device=x1.device)
     ns = torch.empty((B, S), dtype=torch.int32, device=x1.device) if want_counts else None
+    if noalloc:
+        L.check(lib.ph_solve_essential_5pt_noalloc(L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(samples), B, S, N,
+                                                   L.ptr(E), L.ptr(ns), L.stream_ptr()), "ph_solve_essential_5pt_noalloc")
+        return (E, ns) if want_counts else E
     wsb = lib.ph_solve_essential_5pt_ws_bytes(B, S)
     ws = L.workspace(wsb, x1.device)
     L.check(lib.ph_solve_essential_5pt(L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2), L.ptr(samples), B, S, N, L.ptr(E),
