@@ -33,10 +33,10 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: ~2.5 PF dense f16/bf16 = 1024 SIMDs x 32768 FLOP / 32 cyc x 2.4 GHz
-# HBM bytes of l2_filter_kernel alone, rocprofv3 --pmc offline (profiles/r2/l2_matcher_pmc_r2e_64pairs_summary.json, separate
-# passes): FETCH_SIZE 199.2 MB x 2 (the guide's gfx950 correction for 16-B-per-lane streaming reads) + WRITE_SIZE 145.0 MB
-# at 64 pairs = 8.49 MB per pair (query rows 4.19 + tile images 2.13 read, candidate lists 2.27 written)
-FILTER_HBM_BYTES_AT_32_PAIRS = 271.7e6
+# HBM bytes of l2_filter_kernel alone come from the committed counter summary of `tools/gpu_pmc.sh` (rocprofv3 --pmc, separate
+# passes for FETCH_SIZE and WRITE_SIZE; KiB per launch): FETCH_SIZE x 2 (the guide's gfx950 correction for 16-B-per-lane
+# streaming reads) + WRITE_SIZE, scaled from the profile's pair count to this run's.  No file, no number.
+FILTER_PMC_SUMMARY = ("profiles/r3/l2_matcher_pmc_r3_64pairs_summary.json", 64)       # (path under the repo root, pairs per launch)
 N_FEAT, DIM = 8192, 128
 N_SAMPLES = 920                 # minimal samples per pair; ~4.6 real essential matrices each => >= 4096 real hypotheses
 THR_PX = 1.0
@@ -70,6 +70,10 @@ def parse_args():
     ap.add_argument("--sustained-s", type=float, default=2.0,
                     help="seconds of back-to-back steps measured AFTER the timed region for the `sustained` key (0 = skip)")
     ap.add_argument("--check", action="store_true", help="print pose accuracy of the last step against ground truth (stderr)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` object (BASELINE.json configs[2..4], the single-pair latency of configs[1] and "
+                         "the f32-only matcher's step rate; N = 1 only, ~40 s, outside the timed region)")
+    ap.add_argument("--cfg4-pairs", type=int, default=100000, help="pairs of cfg 4's 499,500 that `other_configs` runs (0 = all)")
     return ap.parse_args()
 
 
@@ -194,6 +198,42 @@ def cpu_baseline(batch, n_pairs, threads, E_dev, real_models):
                                      "the rest of the stages as in `value`"}}
 
 
+def filter_traffic(pairs):
+    """(HBM bytes of one l2_filter_kernel launch at `pairs` pairs, where the figure comes from) from the committed PMC summary."""
+    path, prof_pairs = FILTER_PMC_SUMMARY
+    try:
+        d = json.load(open(os.path.join(ROOT, path)))
+    except (OSError, ValueError):
+        return None, f"{path} not found"
+    for name, c in d.items():
+        if "l2_filter_kernel" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            per_launch = (2.0 * c["FETCH_SIZE"]["mean"] + c["WRITE_SIZE"]["mean"]) * 1024.0
+            return per_launch * pairs / prof_pairs, f"{path}: (2 x FETCH_SIZE + WRITE_SIZE) KiB of l2_filter_kernel at {prof_pairs} pairs, scaled to {pairs}"
+    return None, f"{path} holds no l2_filter_kernel counters"
+
+
+def other_configs(args, dev, step_rate):
+    """BASELINE.json's other configurations on this GPU, each with the roofline of its dominant kernel (driver-observed:
+    part of the ONE JSON line).  Scene generation and uploads are outside every timed region."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+    import configs as cf
+    import latency
+    log = lambda msg: print(msg, file=sys.stderr, flush=True)
+    out = {"note": "N = 1, after the headline's timed region; pairs in chunks of 64 alternating over 3 HIP streams, views resident, "
+                   f"{args.samples} minimal samples per pair (>= 4096 real hypotheses, as the headline), refinement on"}
+    t0 = time.perf_counter()
+    out["configs[2] cfg3: 100-camera ring, 4950 pairs, 32768 x 256-bit"] = cf.run_allpairs(3, False, dev, 0, args.samples, log=log)
+    out["configs[3] cfg4 binary: 1000 views, 8192 x 256-bit"] = cf.run_allpairs(4, False, dev, args.cfg4_pairs, args.samples, log=log)
+    out["configs[3] cfg4 f32: 1000 views, 8192 x 128 f32"] = cf.run_allpairs(4, True, dev, args.cfg4_pairs, args.samples, log=log)
+    out["configs[4] cfg5: 32 frames x 65536 correspondences, >= 16384 P3P hypotheses"] = cf.run_cfg5(dev)
+    out["configs[1] literally: ONE pair per batch (and 8), end to end"] = [latency.measure(B, 30, dev) for B in (1, 8)]
+    out["f32_only_matcher"] = step_rate(0)
+    out["seconds_spent"] = time.perf_counter() - t0
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -250,16 +290,17 @@ def main():
     cur = {"buf": batch}
 
     fused = args.precision == 1 and not args.unfused
+    mode = {"precision": args.precision, "fused": fused}
 
     def match():
         b = cur["buf"]
         nq = matching.row_sqnorm(b["desc_q"])
         nt = matching.row_sqnorm(b["desc_t"])
         k = state["step"]
-        if fused:                  # matching + ratio test in one call: same idx / keep, exact re-scores only where needed
+        if mode["fused"]:          # matching + ratio test in one call: same idx / keep, exact re-scores only where needed
             return (*matching.match_l2_ratio(b["desc_q"], b["desc_t"], 0.75, norm_q=nq, norm_t=nt,
                                              kernel_events=kev[k] if state["timed"] else None), "l2_keep")
-        r = matching.match_l2(b["desc_q"], b["desc_t"], norm_q=nq, norm_t=nt, precision=args.precision,
+        r = matching.match_l2(b["desc_q"], b["desc_t"], norm_q=nq, norm_t=nt, precision=mode["precision"],
                               kernel_events=kev[k] if state["timed"] else None)
         return (*r, "l2")
 
@@ -356,6 +397,23 @@ def main():
             sus_dt = float(tmax.item())
         sustained = {"value": world * P * n_sus / sus_dt, "unit": "pairs/s", "steps": n_sus, "seconds": sus_dt}
 
+    def step_rate(precision, n_steps=12):
+        """The same step with another matcher algorithm (identical outputs): pairs/s over n_steps untimed-region steps."""
+        saved = dict(mode)
+        mode.update(precision=precision, fused=False)
+        try:
+            run(3, False)
+            barrier()
+            ts = time.perf_counter()
+            run(n_steps, False)
+            barrier()
+            d = time.perf_counter() - ts
+        finally:
+            mode.update(saved)
+        return {"l2_precision": precision, "matcher": "ph_match_l2_top2 on f32 MFMA (l2_top2_f32_kernel<128>) + ph_ratio_filter_l2",
+                "value": world * P * n_steps / d, "unit": "pairs/s", "steps": n_steps, "ms_per_step": d / n_steps * 1e3,
+                "note": "the headline step with every score on the f32 matrix cores (157.3 TFLOP/s peak): same pose tables, bit for bit"}
+
     # ---- roofline of the dominant kernel.  frac = the kernel ALONE on the device (events recorded by the library around
     # the kernel, one stream, nothing else in flight): the number a rocprofv3 --kernel-trace of `bench.py --streams 1`
     # reproduces.  The brackets of the timed region (other streams' kernels share the CUs then) are kept as contended_*.
@@ -379,10 +437,11 @@ def main():
     kern_us, call_us = float(np.mean(iso_k[1:])), float(np.mean(iso_call[1:]))
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == 0 else PEAK_F16_MFMA_TFLOPS
     achieved = flops / (kern_us * 1e-6) / 1e12
+    traffic, traffic_src = filter_traffic(P) if args.precision == 1 else (None, "not profiled for --precision 0")
     roofline = {
         "kernel": "l2_top2_f32_kernel<128>" if args.precision == 0 else "l2_filter_kernel<4>",
         "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-        "traffic": (FILTER_HBM_BYTES_AT_32_PAIRS * P / 32) if (args.precision == 1 and FILTER_HBM_BYTES_AT_32_PAIRS) else None,
+        "traffic": traffic, "traffic_source": traffic_src,
         "dominant_kernel_us": kern_us,
         "how": "HIP events recorded by ph_match_l2_top2_timed around the kernel alone, on its stream, mean of 5 launches "
                "with nothing else in flight; reproduce: rocprofv3 --kernel-trace --stats -- python3 bench.py --streams 1",
@@ -436,6 +495,10 @@ def main():
         if world == 1 and args.cpu_pairs > 0:
             threads = min(16, os.cpu_count() or 1)
             res["cpu_baseline"] = cpu_baseline(batch, min(args.cpu_pairs, P), threads, out["E_hyp"], real_per_pair)
+        elif world > 1:
+            res["cpu_baseline"] = "skipped (world > 1): the CPU leg is timed on rank 0 at N = 1 only"
+        if world == 1 and not use_dist and not args.no_other_configs:
+            res["other_configs"] = other_configs(args, dev, step_rate)
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
