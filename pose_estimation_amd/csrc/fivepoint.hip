@@ -116,11 +116,16 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
                                                             ph5::Poly5* __restrict__ polys) {
     using namespace coop;
     __shared__ SampleLds lds[kGroupsPerWave];
+    // Three groups of ten lanes in either half of the wave (lanes 30, 31, 62, 63 shadow the group before them, l >= 10):
+    // a ds_bpermute goes through the crossbar in two passes of 32 lanes, and a group that straddled lane 32 made its
+    // exchanges collide with another group's source lanes (SQ_LDS_BANK_CONFLICT: two cycles per shuffle, round 2's layout
+    // of six groups side by side; benchmarks/micro/bpermute_conflicts.hip).
     const int lane = threadIdx.x;
-    const int g = min(lane / kGroup, kGroupsPerWave - 1), l = lane - kGroup * g;     // lanes 60-63 shadow group 5 (l >= 10)
-    const int base = kGroup * g;
+    const int half = lane >> 5, r32 = lane & 31, gg = min(r32 / kGroup, 2);
+    const int g = 3 * half + gg, l = r32 - kGroup * gg;
+    const int base = 32 * half + kGroup * gg;
     const long s = (long)blockIdx.x * kGroupsPerWave + g;
-    const bool active = (lane < kGroup * kGroupsPerWave) && (s < n_samples);
+    const bool active = (r32 < 3 * kGroup) && (s < n_samples);
     const long sc = min(s, n_samples - 1);
     const long b = sc / S;
     SampleLds& L = lds[g];
@@ -344,10 +349,13 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
 // ONE round (256 CUs x 12 waves) instead of a full round and a tail, and a wave fits beside two waves of the L2 filter.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void fivepoint_roots_kernel(const ph5::Poly5* __restrict__ polys, long n_samples,
                                                             float* __restrict__ E_out, int32_t* __restrict__ n_sol) {
+    // lanes: three groups of ten in either half of the wave, as in the polynomial stage (no group straddles lane 32)
     const int lane = threadIdx.x;
-    const int g = lane / 10, k = lane - 10 * g;
+    const int half = lane >> 5, r32 = lane & 31, gg = min(r32 / 10, 2);
+    const int g = 3 * half + gg, k = r32 - 10 * gg;          // k >= 10: idle lanes 30, 31, 62, 63
+    const int base = 32 * half + 10 * gg;
     const long s = (long)blockIdx.x * 6 + g;
-    const bool active = (g < 6) && (s < n_samples);
+    const bool active = (k < 10) && (s < n_samples);
     const ph5::Poly5* Pp = polys + (active ? s : 0);
     const int n = Pp->n;
     double c[11];                                          // the polynomial in registers, zero above its degree
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
 #pragma unroll
         for (int d = 1; d < 10; ++d) {
             int kk = k + d; kk = kk >= 10 ? kk - 10 : kk;
-            const int src = min(10 * g + kk, 63);
+            const int src = base + kk;
             const double zr = __shfl(z.re, src), zi = __shfl(z.im, src);
             if (kk < n) {
                 const ph5::cplx dd = {z.re - zr, z.im - zi};
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     }
     if (n_sol) {
         const unsigned long long votes = __ballot(real);
-        if (active && k == 0) n_sol[s] = (int32_t)__popcll((votes >> (10 * g)) & 0x3ffull);
+        if (active && k == 0) n_sol[s] = (int32_t)__popcll((votes >> base) & 0x3ffull);
     }
 }
 
