@@ -6,7 +6,7 @@ descriptors (dim 128) per view, >= 4096 RANSAC essential-matrix hypotheses (REAL
 minimal sample yields ~4.6 real roots, so 920 samples = 9200 hypothesis slots) per pair.  One step =
 one pass of the hot path over a batch of --pairs such pairs per GPU, inputs resident in HBM:
 
-    row norms -> L2 top-2 (fp16 MFMA candidate filter + exact f32 re-rank) -> ratio test -> compaction -> Philox minimal samples ->
+    L2 top-2 + ratio test (row norms inside the call; fp16 MFMA candidate filter + exact f32 re-rank) -> compaction -> Philox minimal samples ->
     5-point solver (hypothesis generation) -> Sampson scoring of the hypotheses (bail-out) -> best -> inlier mask ->
     decomposition of the winning E (closed form on the device; --decompose host = NumPy SVD) -> 4-candidate
     triangulation + cheirality vote -> pose table row -> LM refinement of the winning pose on the truncated Sampson cost
@@ -57,6 +57,9 @@ def parse_args():
                          "1 = fp16 MFMA candidate filter + exact f32 re-rank")
     ap.add_argument("--unfused", action="store_true",
                     help="ph_match_l2_top2 + ph_ratio_filter_l2 instead of ph_match_l2_ratio (same idx / keep)")
+    ap.add_argument("--given-norms", action="store_true",
+                    help="ph_row_sqnorm of both tables first and the norms handed to the matcher (the two-pass path of rounds 1-2) "
+                         "instead of the matcher computing them in the passes that read the tables anyway")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the batches alternate over: with 2, the latency-bound RANSAC stages of one batch "
                          "run beside the MFMA-bound matcher of the next")
@@ -294,8 +297,10 @@ def main():
 
     def match():
         b = cur["buf"]
-        nq = matching.row_sqnorm(b["desc_q"])
-        nt = matching.row_sqnorm(b["desc_t"])
+        # f32 kernel / --given-norms: ph_row_sqnorm first; default: NULL norms, computed inside the matcher call
+        two_pass = args.given_norms or mode["precision"] == 0
+        nq = matching.row_sqnorm(b["desc_q"]) if two_pass else None
+        nt = matching.row_sqnorm(b["desc_t"]) if two_pass else None
         k = state["step"]
         if mode["fused"]:          # matching + ratio test in one call: same idx / keep, exact re-scores only where needed
             return (*matching.match_l2_ratio(b["desc_q"], b["desc_t"], 0.75, norm_q=nq, norm_t=nt,
@@ -419,7 +424,9 @@ def main():
     # reproduces.  The brackets of the timed region (other streams' kernels share the CUs then) are kept as contended_*.
     flops = 2.0 * N_FEAT * N_FEAT * DIM * P
     contended_us = float(np.mean([hev.elapsed_ms(p) for p in kev])) * 1e3
-    nq_, nt_ = matching.row_sqnorm(batch["desc_q"]), matching.row_sqnorm(batch["desc_t"])
+    two_pass = args.given_norms or args.precision == 0
+    nq_ = matching.row_sqnorm(batch["desc_q"]) if two_pass else None
+    nt_ = matching.row_sqnorm(batch["desc_t"]) if two_pass else None
     iso_k, iso_call = [], []
     for _ in range(6):
         pr = hev.pair()
@@ -451,7 +458,8 @@ def main():
         "contended_note": f"the same kernel inside the timed region, {args.streams} stream(s): other batches' kernels share the CUs",
         "matcher_call_us": call_us, "matcher_call_frac": flops / (call_us * 1e-6) / 1e12 / peak,
         "matcher_call": ("ph_match_l2_ratio" if fused else "ph_match_l2_top2") +
-                        " = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel"
+                        (" = l2_filter_prep_kernel + l2_presplit_kernel + l2_filter_kernel<4> + l2_rerank_kernel (norms handed in)" if two_pass else
+                         " = l2_presplit_norm_kernel + l2_presplit_kernel<fix-up> + l2_filter_kernel<4> + l2_rerank_kernel (row norms computed inside)")
                         if args.precision == 1 else "ph_match_l2_top2 = l2_top2_f32_kernel<128>",
         "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
         "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0)"}
@@ -477,7 +485,7 @@ def main():
             "config": {"workload": "configs[1]: two-view pair, 8192 SIFT-style f32x128 descriptors per view, "
                                    ">= 4096 essential-matrix hypotheses (real models) per pair", "pairs_per_step_per_gpu": P,
                        "features": N_FEAT, "dim": DIM, "hypotheses": real_per_pair, "hypothesis_slots": 10 * S,
-                       "minimal_samples": S, "ratio": 0.75, "matcher": "ph_match_l2_ratio (matching + ratio test, exact re-scores only where the approximate scores do not decide)" if fused else "ph_match_l2_top2 + ph_ratio_filter_l2", "threshold_px": THR_PX, "scoring": "bail-out",
+                       "minimal_samples": S, "ratio": 0.75, "row_norms": "ph_row_sqnorm, two-pass" if (args.given_norms or args.precision == 0) else "inside the matcher call (one read of each table)", "matcher": "ph_match_l2_ratio (matching + ratio test, exact re-scores only where the approximate scores do not decide)" if fused else "ph_match_l2_top2 + ph_ratio_filter_l2", "threshold_px": THR_PX, "scoring": "bail-out",
                        "refine": "none" if args.no_refine else f"device LM, {pipeline.REFINE_ITERS} iterations, Sampson cost truncated at {pipeline.REFINE_TRUNC:g} x threshold",
                        "streams": args.streams, "decompose": args.decompose,
                        "inputs": "pinned host memory, copied over PCIe inside every step (NOT the headline)" if args.h2d else "resident in HBM",

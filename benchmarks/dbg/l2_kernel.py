@@ -1,4 +1,6 @@
-"""Filter-kernel time alone (events recorded by the library around l2_filter_kernel) for several batch sizes."""
+"""Filter-kernel time alone (events recorded by the library around l2_filter_kernel) for several batch sizes.
+L2_MODE=top2 (default): ph_match_l2_top2 with ph_row_sqnorm's norms handed in; L2_MODE=ratio: ph_match_l2_ratio with the norms
+computed inside the call (the pipelines' path: what tools/gpu_pmc.sh profiles for the bench line's traffic figure)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -18,7 +20,10 @@ for P in Ps:
     for k in range(6):
         pr = hev.pair()
         torch.cuda.synchronize()
-        matching.match_l2(a, b, norm_q=nq, norm_t=nt, kernel_events=pr)
+        if os.environ.get("L2_MODE", "top2") == "ratio":
+            matching.match_l2_ratio(a, b, 0.75, kernel_events=pr)
+        else:
+            matching.match_l2(a, b, norm_q=nq, norm_t=nt, kernel_events=pr)
         torch.cuda.synchronize()
         ts.append(hev.elapsed_ms(pr) * 1e3)
     t = float(np.mean(ts[1:]))

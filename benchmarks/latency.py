@@ -30,8 +30,7 @@ def measure(B, iters, dev, n=8192, S=920):
     vq = torch.arange(B, dtype=torch.int32, device=dev)
 
     def eager():
-        nq, nt = matching.row_sqnorm(dq), matching.row_sqnorm(dt)
-        match = lambda: (*matching.match_l2_ratio(dq, dt, 0.75, vq, vq, norm_q=nq, norm_t=nt), "l2_keep")
+        match = lambda: (*matching.match_l2_ratio(dq, dt, 0.75, vq, vq), "l2_keep")       # row norms inside the call
         return pipeline.relative_pose_batch(match, kq, kt, vq, vq, None, thr_sq, n_samples=S, seed=1000, item_key=vq,
                                             want_counts=True)
 

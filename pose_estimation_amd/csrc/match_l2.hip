@@ -324,13 +324,16 @@ extern "C" int ph_match_l2_top2_timed(const float* desc_q, const float* desc_t,
     if (precision != PH_PRECISION_F32 && precision != PH_PRECISION_F16_RERANK) return PH_ERR_UNSUPPORTED;
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || nq == 0) return PH_OK;
-    if (!desc_q || !norm_q || !idx || !d1sq || !d2sq || (nt > 0 && (!desc_t || !norm_t))) return PH_ERR_INVALID_ARG;
+    const bool filter_path = precision == PH_PRECISION_F16_RERANK && dim == 128;
+    const bool own_norms = !norm_q && !norm_t && filter_path;        // the call computes the norms itself (one pass per table)
+    if (!desc_q || !idx || !d1sq || !d2sq || (nt > 0 && !desc_t)) return PH_ERR_INVALID_ARG;
+    if (!own_norms && (!norm_q || (nt > 0 && !norm_t))) return PH_ERR_INVALID_ARG;
     if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
-    if (precision == PH_PRECISION_F16_RERANK && dim == 128) {       // dim 64 takes the f32 kernel: same outputs
+    if (filter_path) {                                               // dim 64 takes the f32 kernel: same outputs
         const L2FilterPlan fp = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
         if (!ws || ws_bytes < fp.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
-        return launch_l2_filter(desc_q, desc_t, norm_q, norm_t, view_q, view_t, n_q, n_t, B, nq, nt, idx, d1sq, d2sq, ws,
-                                (hipStream_t)stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end);
+        return launch_l2_filter(desc_q, desc_t, own_norms ? nullptr : norm_q, own_norms ? nullptr : norm_t, view_q, view_t, n_q, n_t,
+                                B, nq, nt, idx, d1sq, d2sq, ws, (hipStream_t)stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end);
     }
     const L2Plan p = plan_l2(B, nq, nt > 0 ? nt : 1);
     if (p.splits > 1 && (!ws || ws_bytes < p.total || !ph_aligned(ws, 16))) return PH_ERR_WORKSPACE;
@@ -376,11 +379,13 @@ extern "C" int ph_match_l2_ratio(const float* desc_q, const float* desc_t,
     if (dim != 128) return PH_ERR_UNSUPPORTED;             // the fused path is the fp16 filter's (dim 128)
     if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || nq == 0) return PH_OK;
-    if (!desc_q || !norm_q || !idx || !keep || (nt > 0 && (!desc_t || !norm_t))) return PH_ERR_INVALID_ARG;
+    const bool own_norms = !norm_q && !norm_t;                       // the call computes the norms itself (one pass per table)
+    if (!desc_q || !idx || !keep || (nt > 0 && !desc_t)) return PH_ERR_INVALID_ARG;
+    if (!own_norms && (!norm_q || (nt > 0 && !norm_t))) return PH_ERR_INVALID_ARG;
     if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
     const L2FilterPlan fp = plan_l2_filter(B, nq, nt > 0 ? nt : 1);
     if (!ws || ws_bytes < fp.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
-    return launch_l2_filter(desc_q, desc_t, norm_q, norm_t, view_q, view_t, n_q, n_t, B, nq, nt, idx, nullptr, nullptr, ws,
+    return launch_l2_filter(desc_q, desc_t, own_norms ? nullptr : norm_q, own_norms ? nullptr : norm_t, view_q, view_t, n_q, n_t, B, nq, nt, idx, nullptr, nullptr, ws,
                             (hipStream_t)stream, (hipEvent_t)ev_begin, (hipEvent_t)ev_end, ratio * ratio, keep);
 }
 

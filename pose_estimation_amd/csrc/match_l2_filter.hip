@@ -148,6 +148,50 @@ __global__ __launch_bounds__(256) void l2_filter_prep_kernel(const float* __rest
 // into its negated opposite and say anything about a NaN.
 __device__ __forceinline__ bool finite_bits(float x) { return (__float_as_uint(x) & 0x7f800000u) != 0x7f800000u; }
 
+// ---- norms computed inside the call (norm_q == norm_t == NULL): one pass over each table -------------------------------------
+// The row norms are only needed by this call's own kernels, and both tables are read by them anyway: the train table by
+// the kernel that writes the tile images, the query table by the filter.  What stands in the way is the scale — it
+// follows from the LARGEST row norm of a view, which is only known after the pass.  So the pass uses a PROVISIONAL power
+// of two, taken from an estimate of the norm of row 0 of the view, and checks afterwards: it stands if the largest
+// norm, scaled, lies in [2^13, 60000] (fp16's largest number is 65504; the band of the header needs 2^12.5 at the low
+// end, see band2_scaled's callers) — for descriptors normalised to any common length, always.  Otherwise the train
+// view's image is written again with the scale of its true maximum (l2_presplit_kernel<true>, which returns at once for
+// every pair whose provisional scale stood), and a query block scales its rows by its OWN maximum and multiplies the
+// image's presets, which carry the provisional query scale, by the power of two between the two (sixteen extra
+// multiplications per MFMA tile in such blocks only).  Scores of different queries are never compared with each other,
+// so the query scale may differ from block to block; the re-rank reads it per block.
+// Provisional scale of a row: the same value in every lane of the (full) wave that calls it.
+__device__ __forceinline__ float prov_scale(const float* __restrict__ row, int lane) {
+    const float2 x = ((const float2*)row)[lane];              // kDim = 128 = 64 lanes x 2 elements
+    float sum = ph_fma(x.x, x.x, x.y * x.y);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (!finite_bits(sum) || __float_as_uint(sum) == 0u) return 1.0f;
+    int e = 0;
+    frexpf(sqrtf(sum), &e);
+    return abs(15 - e) > 60 ? 1.0f : ldexpf(1.0f, 15 - e);
+}
+__device__ __forceinline__ bool scale_stands(float scaled_max) { return scaled_max >= 8192.0f && scaled_max <= 60000.0f; }
+struct TrainScale { float st, Tmax; bool bad, fixup; };
+__device__ __forceinline__ TrainScale train_scale(uint32_t tmax_sq_bits, float st0) {
+    TrainScale r;
+    r.Tmax = sqrtf(__uint_as_float(tmax_sq_bits));           // largest FINITE squared row norm of the valid train rows
+    const PairScale p = pair_scale(r.Tmax, 1.0f);
+    r.fixup = !scale_stands(st0 * r.Tmax);
+    r.st = r.fixup ? p.st : st0;
+    r.bad = p.bad;
+    return r;
+}
+struct QueryScale { float sq; bool bad; };
+__device__ __forceinline__ QueryScale query_block_scale(float qmax_sq, float sq0) {
+    const float qm = sqrtf(qmax_sq);
+    QueryScale r = {sq0, false};
+    if (scale_stands(sq0 * qm) || __float_as_uint(qmax_sq) == 0u) return r;
+    const PairScale p = pair_scale(1.0f, qm);
+    r.sq = p.sq; r.bad = p.bad;
+    return r;
+}
+constexpr int kQB = 4 * 32 * kQT;   // queries per filter block (kWaves * 32 * kQT)
+
 // Train tile image, written once per (pair, staged tile) and streamed by every query block of the pair straight into
 // LDS (global_load_lds: no registers, no VALU, no LDS write instructions in the filter loop).  It is the LDS image:
 //   uint4 [0, kSub*512)          scaled fp16 rows, MFMA tile after MFMA tile; chunk p of row r at r*16 + (p ^ (r & 15))
@@ -161,31 +205,141 @@ __device__ __forceinline__ bool finite_bits(float x) { return (__float_as_uint(x
 constexpr int kImgRows = kSub * kTR * kCPR;               // uint4
 constexpr int kImgTail = kSub * kTR / 4;                  // uint4
 constexpr int kImg = kImgRows + kImgTail;                 // uint4 per staged tile image
+// FN = false: norms given by the caller ([V][nt], indexed by view), scales from tqmax.
+// FN = true : the fix-up pass of the fused-norms path: norms from the workspace ([B][nt], indexed by pair), and only the
+//             pairs whose provisional train scale did not stand are written again.
+template <bool FN>
 __global__ __launch_bounds__(256) void l2_presplit_kernel(const float* __restrict__ dt, const float* __restrict__ tnorm,
                                                          const int32_t* __restrict__ view_t, const int32_t* __restrict__ n_t,
                                                          int nt, int tiles, int B, const float* __restrict__ tqmax,
+                                                         const uint32_t* __restrict__ tmax_bits, const float* __restrict__ scale0,
                                                          uint4* __restrict__ img) {
     const int b = blockIdx.x / tiles, tile = blockIdx.x % tiles, tid = threadIdx.x;
     const int vt = view_t ? view_t[b] : b;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
-    const PairScale sc = pair_scale(tqmax[b], tqmax[B + b]);
+    float st, sboth;
+    if (FN) {
+        const TrainScale ts = train_scale(tmax_bits[b], scale0[2 * b]);
+        if (!ts.fixup) return;
+        st = ts.st; sboth = ts.st * scale0[2 * b + 1];
+    } else {
+        const PairScale sc = pair_scale(tqmax[b], tqmax[B + b]);
+        st = sc.st; sboth = sc.s;
+    }
+    const float* TN = tnorm + (size_t)(FN ? b : vt) * nt;
     const float4* T = (const float4*)(dt + (size_t)vt * nt * kDim);
     uint4* out = img + (size_t)blockIdx.x * kImg;
     const int t0 = tile * kSR;
 #pragma unroll
     for (int u = 0; u < kImgRows / 256; ++u) {
         const int id = tid + 256 * u, row = id / kCPR, p = id % kCPR;      // row within the staged tile
-        const bool ok = t0 + row < ntv && finite_bits(tnorm[(size_t)vt * nt + min(t0 + row, nt - 1)]);
+        const bool ok = t0 + row < ntv && finite_bits(TN[min(t0 + row, nt - 1)]);
         const float4* src = T + (size_t)(t0 + row) * (kDim / 4) + 2 * p;
         const float4 a = ok ? src[0] : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 c = ok ? src[1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        out[row * kCPR + (p ^ (row & 15))] = to_f16x8(a, c, sc.st);
+        out[row * kCPR + (p ^ (row & 15))] = to_f16x8(a, c, st);
     }
     if (tid < kSub * kTR) {
         const int sub = tid / kTR, row = sub * kTR + (tid & (kTR - 1));
-        const float tn = tnorm[(size_t)vt * nt + min(t0 + row, nt - 1)];
-        ((float*)(out + kImgRows))[tid] = (t0 + row < ntv && finite_bits(tn)) ? -0.5f * tn * sc.s : -INFINITY;
+        const float tn = TN[min(t0 + row, nt - 1)];
+        ((float*)(out + kImgRows))[tid] = (t0 + row < ntv && finite_bits(tn)) ? -0.5f * tn * sboth : -INFINITY;
     }
+}
+
+// Fused-norms path, train side: ONE pass over the train view writes its tile images (provisional scale), its squared row
+// norms (the contract's natural-order fma chain: bit for bit ph_row_sqnorm's) and the maximum of the finite ones (atomic
+// max on the bits: squared norms are >= +0).  A WAVE owns a staged tile of 64 rows and works through it in four slabs of
+// sixteen whole rows: coalesced loads (32 lanes per 512-byte row), every lane converts the float4 it has just loaded and
+// stores its 8 bytes of the image (32 lanes = one 256-byte image row: whole cache lines), the slab goes through an 8 KB
+// LDS block of the wave's own, and lanes 0-15 sum one row each in natural order.  No block barrier.
+// (Tried first: one block per tile with a 32 KB LDS copy and one lane per row behind a barrier, 112 us per 64 x 8192
+// rows; the chain as a systolic pass through the sixteen lanes that hold a row's chunks, 257 us; slabs of 64 rows x 128
+// bytes as in ph_row_sqnorm, every lane busy in the chain but 64-byte pieces of image rows per store, 102 us.)
+__global__ __launch_bounds__(256) void l2_presplit_norm_kernel(const float* __restrict__ dt, const float* __restrict__ dq,
+                                                              const int32_t* __restrict__ view_t, const int32_t* __restrict__ view_q,
+                                                              const int32_t* __restrict__ n_t, int nt, int nq, int tiles, int n_wtiles,
+                                                              float* __restrict__ tnorm_ws, uint32_t* __restrict__ tmax_bits,
+                                                              float* __restrict__ scale0, uint4* __restrict__ img) {
+    static_assert(kSR == 64 && kDim == 128 && kCPR == 16, "a wave per staged tile, slabs of sixteen rows");
+    __shared__ float4 blk[4][16 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wt = blockIdx.x * 4 + wave;                    // (pair, staged tile) of this wave
+    if (wt >= n_wtiles) return;                              // wave-uniform; no block barrier below
+    const int b = wt / tiles, tile = wt % tiles;
+    const int vt = view_t ? view_t[b] : b, vq = view_q ? view_q[b] : b;
+    const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
+    const float4* T = (const float4*)(dt + (size_t)vt * nt * kDim);
+    uint4* out4 = img + (size_t)wt * kImg;
+    uint2* out = (uint2*)out4;
+    const int t0 = tile * kSR;
+    float4* my = blk[wave];
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the LDS block is this wave's own; its LDS operations complete in order
+        __builtin_amdgcn_wave_barrier();
+    };
+    const int ci = lane & 31, rh = lane >> 5;                // float4 of the row, which of the two rows of a load
+    float4 v[8];
+    auto fetch = [&](int slab) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 16 * slab + 2 * i + rh;
+            v[i] = (t0 + r < ntv) ? T[(size_t)(t0 + r) * 32 + ci] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
+    // (after the first slab's loads were issued: row 0 of either view is one more memory round trip)
+    const float st0 = prov_scale(dt + (size_t)vt * nt * kDim, lane);
+    const float sq0 = prov_scale(dq + (size_t)vq * nq * kDim, lane);
+    if (tile == 0 && lane == 0) { scale0[2 * b] = st0; scale0[2 * b + 1] = sq0; }
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int slab = 0; slab < 4; ++slab) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rl = 2 * i + rh, r = 16 * slab + rl;
+            my[rl * 32 + (ci ^ rl)] = v[i];
+            // this lane's half of image chunk ci / 2 of row r: four fp16
+            const _Float16 h0 = (_Float16)(v[i].x * st0), h1 = (_Float16)(v[i].y * st0), h2 = (_Float16)(v[i].z * st0), h3 = (_Float16)(v[i].w * st0);
+            uint2 w;
+            w.x = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+            w.y = (uint32_t)__builtin_bit_cast(unsigned short, h2) | ((uint32_t)__builtin_bit_cast(unsigned short, h3) << 16);
+            out[(r * kCPR + ((ci >> 1) ^ (r & 15))) * 2 + (ci & 1)] = w;
+        }
+        if (slab + 1 < 4) fetch(slab + 1);
+        wave_sync();
+        if (lane < 16) {                                     // one row per lane, natural order
+            float acc = 0.0f;
+#pragma unroll 16
+            for (int k = 0; k < 32; ++k) {
+                const float4 x = my[lane * 32 + (k ^ lane)];
+                acc = ph_fma(x.x, x.x, acc); acc = ph_fma(x.y, x.y, acc);
+                acc = ph_fma(x.z, x.z, acc); acc = ph_fma(x.w, x.w, acc);
+            }
+            const int r = 16 * slab + lane;
+            const bool valid = t0 + r < ntv, ok = valid && finite_bits(acc);
+            ((float*)(out4 + kImgRows))[r] = ok ? -0.5f * acc * (sq0 * st0) : -INFINITY;
+            if (valid) tnorm_ws[(size_t)b * nt + t0 + r] = acc;
+            if (ok) mx = max(mx, __float_as_uint(acc));
+            if (valid && !ok) {                              // outside the contract, rare: the row becomes a padded row
+                __atomic_thread_fence(__ATOMIC_RELEASE);     // behind the image stores of this wave's other lanes
+#pragma unroll
+                for (int q = 0; q < kCPR; ++q) out4[r * kCPR + q] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        wave_sync();
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 0 && mx != 0u) atomicMax(tmax_bits + b, mx);           // one atomic per tile
+}
+// the "no neighbour" outputs of a call without train rows (fused-norms path: nothing else to do)
+__global__ __launch_bounds__(256) void l2_none_kernel(size_t n, int32_t* __restrict__ idx, float* __restrict__ d1sq,
+                                                     float* __restrict__ d2sq, int32_t* __restrict__ keep) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    idx[i] = PH_NO_INDEX;
+    if (d1sq) d1sq[i] = INFINITY;
+    if (d2sq) d2sq[i] = INFINITY;
+    if (keep) keep[i] = 0;
 }
 
 // One LDS-DMA instruction: every active lane copies 16 bytes from its own global address to LDS byte address
@@ -208,15 +362,22 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-template <int WAVES>
+// FN = true: the fused-norms path — the query rows' squared norms are computed HERE (natural-order chain, handed between
+// the two lane halves that hold a row's odd and even 8-element chunks) and written to qnorm_ws [B][nq]; the scales are the
+// provisional ones of l2_presplit_norm_kernel unless they did not stand (see above); the block's query scale goes to
+// qscale [B][nqb] for the re-rank.
+template <int WAVES, bool FN>
 __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     const float* __restrict__ dq, const uint4* __restrict__ img, int tiles,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int rows_per_split,
     const float* __restrict__ qnorm, const float* __restrict__ tqmax,
-    int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B) {
+    int32_t* __restrict__ cnt, int2* __restrict__ list, int slots, int nqb, int B,
+    float* __restrict__ qnorm_ws, const uint32_t* __restrict__ tmax_bits, const float* __restrict__ scale0,
+    float* __restrict__ qscale) {
     constexpr int NT = WAVES * 64;
+    static_assert(NT / 64 * 32 * kQT == kQB, "queries per block");
     static_assert(WAVES == 4 && kImgRows % 256 == 0 && kImgTail % 4 == 0 && kImgTail <= 256 && kSub * kTR <= 256, "staging deal");
     __shared__ uint4 smem[(kDepth + 1) * kImg];   // ring of kDepth + 1 staged tiles; ONE array: a second LDS object beside an LDS-DMA
                                                   // target makes the compiler drain the DMA before every LDS read
@@ -238,9 +399,17 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
     const float* Q = dq + (size_t)vq * nq * kDim;
-    const float* QN = qnorm + (size_t)vq * nq;
-    const float Tm = tqmax[b], Qm = tqmax[B + b];
-    const PairScale sc = pair_scale(Tm, Qm);
+    float Tm, Qm, sq_use, s_use;                     // largest norms (Qm: what the band's sub-range term needs), query scale, sq * st
+    float sq0 = 1.0f, st_use = 1.0f;
+    if (FN) {
+        const TrainScale ts = train_scale(tmax_bits[b], scale0[2 * b]);
+        sq0 = scale0[2 * b + 1];
+        Tm = ts.Tmax; st_use = ts.st; sq_use = sq0; Qm = 0.0f; s_use = 0.0f;       // Qm, s_use: once the block's scale is settled
+    } else {
+        Tm = tqmax[b]; Qm = tqmax[B + b];
+        const PairScale sc = pair_scale(Tm, Qm);
+        sq_use = sc.sq; st_use = sc.st; s_use = sc.s;
+    }
     const uint4* IMG = img + (size_t)b * tiles * kImg;
     // the pair's candidate lists as a raw buffer (at most 4 GB per pair: nq * slots * 256 bytes)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -250,25 +419,87 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
 
     // B fragments: query row (qw0 + ct*32 + li), elements 16s + 8h .. +7, scaled, as fp16
     uint4 bh[kQT][kNS];
-    float thr[kQT], eps2[kQT], a1[kQT], a2[kQT];
+    float thr[kQT], eps2[kQT], a1[kQT], a2[kQT], qn2[kQT];
     size_t qoff[kQT];
     unsigned lpos[kQT], lend[kQT];                   // byte offsets in the pair's lists: where this lane's private segment takes its
                                                      // next entry (it keeps counting beyond the end: overflow), and the segment's end
+    auto convert = [&](int ct, float scale) {
+        const float4* qrow = (const float4*)(Q + (size_t)min(qw0 + ct * 32 + li, nq - 1) * kDim);
+#pragma unroll
+        for (int s = 0; s < kNS; ++s) bh[ct][s] = to_f16x8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], scale);
+    };
+    float resc = 1.0f;                               // FN: (this block's query scale) / (the provisional one in the image's presets)
+    bool blk_bad = false;                            // FN: the block's query norms are beyond the scaled arithmetic: exact path
+    if (FN) {
+        float blk_max = 0.0f;
+#pragma unroll
+        for (int ct = 0; ct < kQT; ++ct) {
+            const int qi = qw0 + ct * 32 + li;
+            const float4* qrow = (const float4*)(Q + (size_t)min(qi, nq - 1) * kDim);
+            // |q|^2 in natural element order: chunk 2s sits in the lower lane half, chunk 2s + 1 in the upper one
+            float acc = 0.0f;
+#pragma unroll
+            for (int s = 0; s < kNS; ++s) {
+                const float4 x = qrow[4 * s + 2 * h], y = qrow[4 * s + 2 * h + 1];
+                bh[ct][s] = to_f16x8(x, y, sq0);
+                float lo, hi;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {           // half 0: the lower lanes' chain step is the valid one, then the upper lanes'
+                    float r = acc;
+                    r = ph_fma(x.x, x.x, r); r = ph_fma(x.y, x.y, r); r = ph_fma(x.z, x.z, r); r = ph_fma(x.w, x.w, r);
+                    r = ph_fma(y.x, y.x, r); r = ph_fma(y.y, y.y, r); r = ph_fma(y.z, y.z, r); r = ph_fma(y.w, y.w, r);
+                    both_halves(r, lo, hi);
+                    acc = half == 0 ? lo : hi;
+                }
+            }
+            qn2[ct] = acc;
+            if (split == 0 && h == 0 && qi < nq) qnorm_ws[(size_t)b * nq + qi] = acc;
+            if (qi < nqv && finite_bits(acc)) blk_max = fmaxf(blk_max, acc);
+        }
+        for (int o = 32; o > 0; o >>= 1) blk_max = fmaxf(blk_max, __shfl_xor(blk_max, o));
+        float* red = (float*)smem;                   // the staging ring is not in use yet
+        if (lane == 0) red[wave] = blk_max;
+        __syncthreads();
+        blk_max = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();                             // everybody has read before the first copy lands
+        const QueryScale qs = query_block_scale(blk_max, sq0);
+        blk_bad = qs.bad;
+        sq_use = qs.sq;
+        if (sq_use != sq0) {                         // block-uniform, rare: rows again at the block's own scale
+            resc = sq_use / sq0;
+#pragma unroll
+            for (int ct = 0; ct < kQT; ++ct) convert(ct, sq_use);
+        }
+        s_use = sq_use * st_use;
+        Qm = 16384.0f / sq_use;                      // the band's sub-range term needs a bound of 2^12.5 / sq (header)
+        if (split == 0 && tid == 0) qscale[(size_t)b * nqb + xb] = sq_use;
+    } else {
+        const float* QN = qnorm + (size_t)vq * nq;
+#pragma unroll
+        for (int ct = 0; ct < kQT; ++ct) {
+            convert(ct, sq_use);
+            qn2[ct] = QN[min(qw0 + ct * 32 + li, nq - 1)];
+        }
+    }
 #pragma unroll
     for (int ct = 0; ct < kQT; ++ct) {
         const int qi = qw0 + ct * 32 + li;
-        const float4* qrow = (const float4*)(Q + (size_t)min(qi, nq - 1) * kDim);
-#pragma unroll
-        for (int s = 0; s < kNS; ++s) bh[ct][s] = to_f16x8(qrow[4 * s + 2 * h], qrow[4 * s + 2 * h + 1], sc.sq);
-        const bool live = qi < nqv;
+        const bool live = qi < nqv && !blk_bad;
         qoff[ct] = ((size_t)b * nq + min(qi, nq - 1)) * slots + (2 * split + h);
         lpos[ct] = (unsigned)(((size_t)min(qi, nq - 1) * slots + (2 * split + h)) * kCapH * sizeof(int2));
         lend[ct] = lpos[ct] + (unsigned)(kCapH * sizeof(int2));
-        eps2[ct] = band2_scaled(QN[min(qi, nq - 1)], Tm, Qm, sc.s);
+        eps2[ct] = band2_scaled(qn2[ct], Tm, Qm, s_use);
         thr[ct] = live ? -3.0e38f : INFINITY;           // finite floor: the -inf score of a padded row never reaches it;
                                                          // a dead lane never has a candidate
         a1[ct] = -INFINITY; a2[ct] = -INFINITY;
     }
+    if (blk_bad) {                                   // every live query of the block: "overflowed" -> the re-rank's exact scan
+#pragma unroll
+        for (int ct = 0; ct < kQT; ++ct)
+            if (qw0 + ct * 32 + li < nqv) cnt[qoff[ct]] = kCapH + 1;
+        return;
+    }
+    const float resc_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(resc)));
 
     const int t_begin = split * rows_per_split;          // a multiple of kSR
     const int t_end = min(ntv, t_begin + rows_per_split);
@@ -340,6 +571,10 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
         for (int g = 0; g < 4; ++g) {
             const float4 z = *(const float4*)(sm + (poff + (pbase + 32u * g)));     // rows 8g + 4h .. +3
             preset[4 * g + 0] = z.x; preset[4 * g + 1] = z.y; preset[4 * g + 2] = z.z; preset[4 * g + 3] = z.w;
+        }
+        if (FN && resc_u != 1.0f) {                  // wave-uniform, rare: the image's presets carry the provisional query scale
+#pragma unroll
+            for (int r = 0; r < 16; ++r) preset[r] *= resc_u;
         }
         af[1] = frag(1);
         __builtin_amdgcn_sched_barrier(0);
@@ -524,14 +759,17 @@ struct RerankLds {
 // d1sq < r2 * d2sq one way or the other the query is done (a kept one also needs the separated best row) — 99 of 100
 // are: a planted match wins by far, a non-match fails by far; the others take the exact path, so the outputs never differ
 // from the two-kernel path.
-template <bool FUSE>
+// FN = the fused-norms path: tnorm / qnorm are the workspace copies ([B][nt], [B][nq], indexed by pair), the train scale
+// follows from (tmax_bits, scale0) as in the filter, the query scale is the filter block's (qscale [B][nqb]).
+template <bool FUSE, bool FN>
 __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const float* __restrict__ dq, const float* __restrict__ dt,
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
     const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t, int B, int nq, int nt,
     const float* __restrict__ tnorm, const float* __restrict__ qnorm,
     const float* __restrict__ tqmax, const int32_t* __restrict__ cnt, const int2* __restrict__ list, int slots,
-    int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq, float r2, int32_t* __restrict__ keep_out) {
+    int32_t* __restrict__ idx, float* __restrict__ d1sq, float* __restrict__ d2sq, float r2, int32_t* __restrict__ keep_out,
+    const uint32_t* __restrict__ tmax_bits, const float* __restrict__ scale0, const float* __restrict__ qscale, int nqb) {
     __shared__ RerankLds lds[4];
     // blocks of one pair share one residue of the block id mod 8 (one XCD, one L2 for the pair's train rows)
     constexpr int QPB = 256 / kRL;
@@ -554,7 +792,8 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     const size_t o = (size_t)b * nq + min(qi, nq - 1);    // (pair, query) index
     const float4* q = (const float4*)(dq + ((size_t)vq * nq + min(qi, nq - 1)) * kDim);
     const float4* Tt = (const float4*)(dt + (size_t)vt * nt * kDim);
-    const float* TN = tnorm + (size_t)vt * nt;
+    const float* TN = tnorm + (size_t)(FN ? b : vt) * nt;
+    const float* QN = qnorm + (size_t)(FN ? b : vq) * nq;
     RerankLds& L = lds[wave];
     auto wave_sync = [] {                                  // the LDS block belongs to this wave alone; its LDS operations
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // complete in order: only the compiler needs the fence
@@ -618,9 +857,18 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
     // The two rows with the largest approximate scores are in the list (they passed every running bound), so the
     // second-largest LISTED sA is the query's true second-largest, and only rows with sA >= that - 2e can be one of
     // the exact top-2: typically 2-3 of the ~11 listed rows.
-    const float Tm = tqmax[b], Qm = tqmax[B + b];
-    const PairScale sc = pair_scale(Tm, Qm);
-    const float qn_i = qnorm[(size_t)vq * nq + min(qi, nq - 1)];
+    float Tm, Qm;
+    PairScale sc;
+    if (FN) {
+        const TrainScale ts = train_scale(tmax_bits[b], scale0[2 * b]);
+        sc.sq = qscale[(size_t)b * nqb + min(qi, nq - 1) / kQB];
+        sc.st = ts.st; sc.s = sc.sq * sc.st; sc.bad = ts.bad;
+        Tm = ts.Tmax; Qm = 16384.0f / sc.sq;              // as in the filter
+    } else {
+        Tm = tqmax[b]; Qm = tqmax[B + b];
+        sc = pair_scale(Tm, Qm);
+    }
+    const float qn_i = QN[min(qi, nq - 1)];
     const float band = band2_scaled(qn_i, Tm, Qm, sc.s);   // 2e, scaled
     const float bound = p2 - band;
     overflow |= sc.bad;                                    // wave-uniform per pair: the lists of such a pair are not used
@@ -751,7 +999,7 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
         bi = other ? obi : bi;
     }
     if (sl == 0 && qi < nq) {
-        const float qn = qnorm[(size_t)vq * nq + qi];
+        const float qn = QN[qi];
         const float d1 = (bi >= 0) ? fmaxf(0.0f, ph_fma(-2.0f, m1, qn)) : INFINITY;
         const float d2 = (m2 > -INFINITY) ? fmaxf(0.0f, ph_fma(-2.0f, m2, qn)) : INFINITY;
         if (FUSE) {
@@ -789,7 +1037,12 @@ L2FilterPlan plan_l2_filter(int B, int nq, int nt) {
     p.off_cnt = ((size_t)2 * B * sizeof(float) + 255) / 256 * 256;
     p.off_list = p.off_cnt + ((size_t)B * nq * p.slots * sizeof(int32_t) + 255) / 256 * 256;
     p.off_img = p.off_list + ((size_t)B * nq * p.slots * kCapH * sizeof(int2) + 255) / 256 * 256;
-    p.total = p.off_img + (size_t)B * p.tiles * kImg * sizeof(uint4);
+    // the fused-norms path's own arrays: squared row norms of the call's views, per pair; largest train norm (bits),
+    // provisional scales, per-block query scales
+    p.off_tnorm = p.off_img + ((size_t)B * p.tiles * kImg * sizeof(uint4) + 255) / 256 * 256;
+    p.off_qnorm = p.off_tnorm + ((size_t)B * nt * sizeof(float) + 255) / 256 * 256;
+    p.off_misc = p.off_qnorm + ((size_t)B * nq * sizeof(float) + 255) / 256 * 256;
+    p.total = p.off_misc + ((size_t)B * (3 + ph_ceil_div(nq, kQB)) * sizeof(float) + 255) / 256 * 256;
     return p;
 }
 
@@ -802,25 +1055,62 @@ int launch_l2_filter(const float* desc_q, const float* desc_t, const float* norm
     int32_t* cnt = (int32_t*)((char*)ws + p.off_cnt);
     int2* list = (int2*)((char*)ws + p.off_list);
     uint4* img = (uint4*)((char*)ws + p.off_img);
+    const int nqb = ph_ceil_div(nq, kQB);
+    const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
+    const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
+    if (!norm_q) {
+        // ---- norms computed here: one pass over each table (see l2_presplit_norm_kernel)
+        if (nt <= 0) {                                           // no train rows: every query reports "no neighbour"
+            const size_t n = (size_t)B * nq;
+            hipLaunchKernelGGL(l2_none_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, idx, d1sq, d2sq, keep);
+            return ph_launch_status();
+        }
+        float* tnorm_ws = (float*)((char*)ws + p.off_tnorm);
+        float* qnorm_ws = (float*)((char*)ws + p.off_qnorm);
+        uint32_t* tmax_bits = (uint32_t*)((char*)ws + p.off_misc);                // [B]
+        float* scale0 = (float*)((char*)ws + p.off_misc) + B;                     // [B][2]: provisional train, query scale
+        float* qscale = scale0 + 2 * (size_t)B;                                   // [B][nqb]
+        const unsigned img_blocks = (unsigned)((size_t)B * p.tiles);
+        ph_zero_words(tmax_bits, (size_t)B, st);
+        hipLaunchKernelGGL(l2_presplit_norm_kernel, dim3((img_blocks + 3) / 4), dim3(256), 0, st, desc_t, desc_q, view_t, view_q, n_t,
+                           nt, nq, p.tiles, (int)img_blocks, tnorm_ws, tmax_bits, scale0, img);
+        hipLaunchKernelGGL(l2_presplit_kernel<true>, dim3(img_blocks), dim3(256), 0, st, desc_t, (const float*)tnorm_ws, view_t, n_t,
+                           nt, p.tiles, B, (const float*)nullptr, (const uint32_t*)tmax_bits, (const float*)scale0, img);
+        if (ev_begin && hipEventRecord(ev_begin, st) != hipSuccess) return PH_ERR_LAUNCH;
+        hipLaunchKernelGGL((l2_filter_kernel<kWaves, true>), grid, dim3(kWaves * 64), 0, st, desc_q, img, p.tiles, view_q, view_t, n_q,
+                           n_t, nq, nt, p.rows_per_split, (const float*)nullptr, (const float*)nullptr, cnt, list, p.slots, nqb, B,
+                           qnorm_ws, (const uint32_t*)tmax_bits, (const float*)scale0, qscale);
+        if (ev_end && hipEventRecord(ev_end, st) != hipSuccess) return PH_ERR_LAUNCH;
+        if (keep)
+            hipLaunchKernelGGL((l2_rerank_kernel<true, true>), dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                               view_t, n_q, n_t, B, nq, nt, (const float*)tnorm_ws, (const float*)qnorm_ws, (const float*)nullptr, cnt,
+                               list, p.slots, idx, d1sq, d2sq, ratio_sq, keep, (const uint32_t*)tmax_bits, (const float*)scale0,
+                               (const float*)qscale, nqb);
+        else
+            hipLaunchKernelGGL((l2_rerank_kernel<false, true>), dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                               view_t, n_q, n_t, B, nq, nt, (const float*)tnorm_ws, (const float*)qnorm_ws, (const float*)nullptr, cnt,
+                               list, p.slots, idx, d1sq, d2sq, 0.0f, (int32_t*)nullptr, (const uint32_t*)tmax_bits,
+                               (const float*)scale0, (const float*)qscale, nqb);
+        return ph_launch_status();
+    }
     hipLaunchKernelGGL(l2_filter_prep_kernel, dim3(B), dim3(256), 0, st, norm_t, norm_q, view_t, view_q, n_t, n_q, nq, nt,
                        p.slots, B, nt > 0 ? 0 : 1, tqmax, cnt);
     if (nt > 0) {
-        hipLaunchKernelGGL(l2_presplit_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, desc_t, norm_t, view_t, n_t,
-                           nt, p.tiles, B, tqmax, img);
-        const int nqb = ph_ceil_div(nq, kWaves * 32 * kQT);
-        const dim3 grid((unsigned)((size_t)nqb * p.splits * B));
+        hipLaunchKernelGGL(l2_presplit_kernel<false>, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, desc_t, norm_t, view_t,
+                           n_t, nt, p.tiles, B, (const float*)tqmax, (const uint32_t*)nullptr, (const float*)nullptr, img);
         if (ev_begin && hipEventRecord(ev_begin, st) != hipSuccess) return PH_ERR_LAUNCH;
-        hipLaunchKernelGGL(l2_filter_kernel<kWaves>, grid, dim3(kWaves * 64), 0, st, desc_q, img, p.tiles, view_q, view_t, n_q, n_t,
-                           nq, nt, p.rows_per_split, norm_q, tqmax, cnt, list, p.slots, nqb, B);
+        hipLaunchKernelGGL((l2_filter_kernel<kWaves, false>), grid, dim3(kWaves * 64), 0, st, desc_q, img, p.tiles, view_q, view_t,
+                           n_q, n_t, nq, nt, p.rows_per_split, norm_q, (const float*)tqmax, cnt, list, p.slots, nqb, B,
+                           (float*)nullptr, (const uint32_t*)nullptr, (const float*)nullptr, (float*)nullptr);
         if (ev_end && hipEventRecord(ev_end, st) != hipSuccess) return PH_ERR_LAUNCH;
     }
-    const size_t rr_blocks = (size_t)B * ph_ceil_div(nq, 256 / kRL);
     if (keep)
-        hipLaunchKernelGGL(l2_rerank_kernel<true>, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
-                           view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tqmax, cnt, list, p.slots, idx, d1sq, d2sq, ratio_sq, keep);
+        hipLaunchKernelGGL((l2_rerank_kernel<true, false>), dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                           view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, (const float*)tqmax, cnt, list, p.slots, idx, d1sq, d2sq,
+                           ratio_sq, keep, (const uint32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, nqb);
     else
-        hipLaunchKernelGGL(l2_rerank_kernel<false>, dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
-                           view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, tqmax, cnt, list, p.slots, idx, d1sq, d2sq, 0.0f,
-                           (int32_t*)nullptr);
+        hipLaunchKernelGGL((l2_rerank_kernel<false, false>), dim3((unsigned)rr_blocks), dim3(256), 0, st, desc_q, desc_t, view_q,
+                           view_t, n_q, n_t, B, nq, nt, norm_t, norm_q, (const float*)tqmax, cnt, list, p.slots, idx, d1sq, d2sq,
+                           0.0f, (int32_t*)nullptr, (const uint32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, nqb);
     return ph_launch_status();
 }

@@ -15,6 +15,8 @@ import torch
 from . import _lib as L
 
 MAX_ITEMS = 65535
+OWN_NORMS = True    # calls without norm_q / norm_t let the library compute the norms inside the matcher call (False: ph_row_sqnorm
+                    # first, the two-pass path — the tests run both)
 
 
 def _views(table, view, name):
@@ -81,7 +83,9 @@ def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, preci
     ``L.PRECISION_F32`` scores every pair of rows on the f32 MFMA; ``L.PRECISION_F16_RERANK`` (default) filters
     candidates with one fp16 MFMA product per score (inside a proven error band) and re-ranks them with the exact chain.
 
-    norm_q / norm_t: cached ``row_sqnorm`` of the tables (computed here when not given).
+    norm_q / norm_t: cached ``row_sqnorm`` of the tables — views that many pairs share (cfg 3 / 4).  When neither is given the
+    fp16-filter path computes the norms inside the call, fused into the passes that read the two tables anyway (one read of
+    each table instead of two); the outputs are the same bit for bit.
     kernel_events: optional pair of raw hipEvent_t handles (ints) recorded around the call's dominant kernel alone
     (``ph_match_l2_top2_timed``; measurement only, at most one launch chunk).
     """
@@ -99,8 +103,12 @@ def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, preci
         raise ValueError(f"pair lists differ in length: {B} vs {Bt}")
     n_q, n_t = L.opt_i32(n_q, B, "n_q"), L.opt_i32(n_t, B, "n_t")
     dev = desc_q.device
-    norm_q = row_sqnorm(desc_q) if norm_q is None else L.dev(norm_q, torch.float32, "norm_q")
-    norm_t = (norm_q if desc_t is desc_q else row_sqnorm(desc_t)) if norm_t is None else L.dev(norm_t, torch.float32, "norm_t")
+    # no norms given: the fp16-filter path computes them inside the call, in the passes that read the tables anyway (NULL to
+    # the library); the f32 kernel needs them up front
+    own_norms = OWN_NORMS and norm_q is None and norm_t is None and int(precision) == L.PRECISION_F16_RERANK and dim == 128
+    if not own_norms:
+        norm_q = row_sqnorm(desc_q) if norm_q is None else L.dev(norm_q, torch.float32, "norm_q")
+        norm_t = (norm_q if desc_t is desc_q else row_sqnorm(desc_t)) if norm_t is None else L.dev(norm_t, torch.float32, "norm_t")
     idx = torch.empty((B, nq), dtype=torch.int32, device=dev)
     d1 = torch.empty((B, nq), dtype=torch.float32, device=dev)
     d2 = torch.empty_like(d1)
@@ -111,8 +119,8 @@ def match_l2(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, preci
         sl = lambda t: None if t is None else t[s:e]
         q = desc_q if view_q is not None else desc_q[s:e]
         t = desc_t if view_t is not None else desc_t[s:e]
-        qn = norm_q if view_q is not None else norm_q[s:e]
-        tn = norm_t if view_t is not None else norm_t[s:e]
+        qn = None if own_norms else (norm_q if view_q is not None else norm_q[s:e])
+        tn = None if own_norms else (norm_t if view_t is not None else norm_t[s:e])
         args = (L.ptr(q), L.ptr(t), L.ptr(qn), L.ptr(tn), L.ptr(sl(view_q)), L.ptr(sl(view_t)),
                 L.ptr(sl(n_q)), L.ptr(sl(n_t)), nb, nq, nt, dim, precision,
                 L.ptr(idx[s:e]), L.ptr(d1[s:e]), L.ptr(d2[s:e]), L.ptr(ws), wsb, L.stream_ptr())
@@ -153,8 +161,10 @@ def match_l2_ratio(desc_q, desc_t, ratio, view_q=None, view_t=None, n_q=None, n_
         raise ValueError(f"pair lists differ in length: {B} vs {Bt}")
     n_q, n_t = L.opt_i32(n_q, B, "n_q"), L.opt_i32(n_t, B, "n_t")
     dev = desc_q.device
-    norm_q = row_sqnorm(desc_q) if norm_q is None else L.dev(norm_q, torch.float32, "norm_q")
-    norm_t = (norm_q if desc_t is desc_q else row_sqnorm(desc_t)) if norm_t is None else L.dev(norm_t, torch.float32, "norm_t")
+    own_norms = OWN_NORMS and norm_q is None and norm_t is None        # computed inside the call (NULL to the library), one pass per table
+    if not own_norms:
+        norm_q = row_sqnorm(desc_q) if norm_q is None else L.dev(norm_q, torch.float32, "norm_q")
+        norm_t = (norm_q if desc_t is desc_q else row_sqnorm(desc_t)) if norm_t is None else L.dev(norm_t, torch.float32, "norm_t")
     idx = torch.empty((B, nq), dtype=torch.int32, device=dev)
     keep = torch.empty((B, nq), dtype=torch.int32, device=dev)
     ev = kernel_events if kernel_events is not None else (None, None)
@@ -165,8 +175,8 @@ def match_l2_ratio(desc_q, desc_t, ratio, view_q=None, view_t=None, n_q=None, n_
         sl = lambda t: None if t is None else t[s:e]
         q = desc_q if view_q is not None else desc_q[s:e]
         t = desc_t if view_t is not None else desc_t[s:e]
-        qn = norm_q if view_q is not None else norm_q[s:e]
-        tn = norm_t if view_t is not None else norm_t[s:e]
+        qn = None if own_norms else (norm_q if view_q is not None else norm_q[s:e])
+        tn = None if own_norms else (norm_t if view_t is not None else norm_t[s:e])
         L.check(lib.ph_match_l2_ratio(L.ptr(q), L.ptr(t), L.ptr(qn), L.ptr(tn), L.ptr(sl(view_q)), L.ptr(sl(view_t)),
                                       L.ptr(sl(n_q)), L.ptr(sl(n_t)), nb, nq, nt, dim, float(ratio),
                                       L.ptr(idx[s:e]), L.ptr(keep[s:e]), L.ptr(ws), wsb, L.stream_ptr(), ev[0], ev[1]),

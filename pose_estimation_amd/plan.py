@@ -26,8 +26,8 @@ class RelativePosePlan:
     """desc_q / desc_t: resident descriptor tables ``[V, n, 128]`` float32 (L2) or ``[V, n, 32]`` uint8 (Hamming);
     kp_q / kp_t: ``[V, n, 2]`` normalised keypoints; B pairs per replay.
 
-    fresh_norms=True recomputes the row norms of both float tables inside every replay (a front end that hands over new
-    views every time — what bench.py's headline step does); False computes them once, here (views resident across calls)."""
+    fresh_norms=True lets the matcher compute the row norms of the pairs' views inside every replay (a front end that hands over
+    new views every time — what bench.py's headline step does); False computes them once, here (views resident across calls)."""
 
     def __init__(self, desc_q, desc_t, kp_q, kp_t, B, thr_sq, ratio=0.75, n_samples=920, seed=0, refine=True,
                  fresh_norms=True, warmup=2):
@@ -60,8 +60,7 @@ class RelativePosePlan:
     def _chain(self):
         if self.float_desc:
             def match():
-                nq = matching.row_sqnorm(self.desc_q) if self.fresh_norms else self.norm_q
-                nt = (nq if self.desc_t is self.desc_q else matching.row_sqnorm(self.desc_t)) if self.fresh_norms else self.norm_t
+                nq, nt = (None, None) if self.fresh_norms else (self.norm_q, self.norm_t)     # None: computed inside the matcher call
                 return (*matching.match_l2_ratio(self.desc_q, self.desc_t, self.ratio, self.view_q, self.view_t,
                                                  norm_q=nq, norm_t=nt), "l2_keep")
         else:

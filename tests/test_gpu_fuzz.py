@@ -11,6 +11,13 @@ from oracle import oracle as orc
 from pose_estimation_amd import matching, synthetic
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, params=["own_norms", "given_norms"])
+def norms_mode(request, monkeypatch):
+    """Every test of this module runs twice: with the row norms computed inside the matcher call (fused into the passes
+    that read the tables: NULL norms at the C ABI) and with ph_row_sqnorm's norms handed in (the two-pass path)."""
+    monkeypatch.setattr(matching, "OWN_NORMS", request.param == "own_norms")
 _MORE = int(os.environ.get("POSEHOT_FUZZ_SEEDS", "0"))      # extra seeds for a one-off soak run
 
 

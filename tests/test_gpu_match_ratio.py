@@ -12,6 +12,13 @@ from pose_estimation_amd import matching, synthetic
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["own_norms", "given_norms"])
+def norms_mode(request, monkeypatch):
+    """Every test of this module runs twice: with the row norms computed inside the matcher call (fused into the passes
+    that read the tables: NULL norms at the C ABI) and with ph_row_sqnorm's norms handed in (the two-pass path)."""
+    monkeypatch.setattr(matching, "OWN_NORMS", request.param == "own_norms")
+
+
 def _t(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 

@@ -14,6 +14,13 @@ from pose_estimation_amd import matching, synthetic
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["own_norms", "given_norms"])
+def norms_mode(request, monkeypatch):
+    """Every test of this module runs twice: with the row norms computed inside the matcher call (fused into the passes
+    that read the tables: NULL norms at the C ABI) and with ph_row_sqnorm's norms handed in (the two-pass path)."""
+    monkeypatch.setattr(matching, "OWN_NORMS", request.param == "own_norms")
+
+
 def _t(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
@@ -319,3 +326,42 @@ def test_l2_nan_rows_are_never_preferred_and_nothing_faults(device, precision):
     second = np.argsort(d, axis=1)[:, 1]
     same = clean & (idx0 != j0) & (second != j0)
     assert same.sum() > 600 and np.array_equal(idx[same], idx0[same]) and np.array_equal(a[same], a0[same])
+
+
+def test_l2_own_norms_when_the_provisional_scales_do_not_stand(device):
+    """Norms computed inside the call (NULL at the C ABI): the tile images and the query fragments are first scaled by a
+    power of two taken from ROW 0 of either view; inputs whose largest norm that scale does not fit must take the fix-up
+    pass (train) or the block's own scale with re-scaled presets (queries) — and give the f32 kernel's bits, as always.
+    (a) train row 0 a thousand times smaller than the rest; (b) train row 0 all zero; (c) train row 0 huge; (d) query row 0
+    tiny, the second query block (rows 256..511) a hundred times larger than the first, norms inside the third block
+    spread over six decades; (e) both at once, two pairs sharing the tables through view lists, ragged valid counts."""
+    rng = np.random.default_rng(2024)
+    q = synthetic.sift_like(rng, 900, 128); t = synthetic.sift_like(rng, 2500, 128)
+    ta = t.copy(); ta[0] *= 1e-3
+    tb = t.copy(); tb[0] = 0.0
+    tc = t.copy(); tc[0] *= 3e3
+    qd = q.copy(); qd[0] *= 1e-4; qd[256:512] *= 100.0
+    qd[512:768] *= np.exp(rng.uniform(np.log(1e-3), np.log(1e3), (256, 1))).astype(np.float32)
+    saved = matching.OWN_NORMS
+    try:
+        for qq, tt in ((q, ta), (q, tb), (q, tc), (qd, t), (qd, ta)):
+            matching.OWN_NORMS = False
+            want = matching.match_l2(_t(qq[None], device), _t(tt[None], device), precision=0)
+            matching.OWN_NORMS = True
+            got = matching.match_l2(_t(qq[None], device), _t(tt[None], device), precision=1)
+            _assert_same_bits(want, got)
+            idx, keep = matching.match_l2_ratio(_t(qq[None], device), _t(tt[None], device), 0.8)
+            k0 = matching.ratio_filter_l2(*want, 0.8)
+            assert torch.equal(keep, k0) and torch.equal(idx[keep.bool()], want[0][keep.bool()])
+        ri, r1, r2 = orc.match_l2_top2(qd, ta)
+        assert np.array_equal(got[0].cpu().numpy()[0], ri) and np.array_equal(got[1].cpu().numpy()[0].view(np.uint32), r1.view(np.uint32))
+        # (e) view lists + ragged counts
+        tq = _t(np.stack([qd, q]), device); tt = _t(np.stack([ta, tc]), device)
+        vq = _t(np.array([0, 1, 0], np.int32), device); vt = _t(np.array([1, 0, 0], np.int32), device)
+        nq_ = _t(np.array([900, 300, 777], np.int32), device); nt_ = _t(np.array([2500, 1000, 65], np.int32), device)
+        matching.OWN_NORMS = False
+        want = matching.match_l2(tq, tt, vq, vt, nq_, nt_, precision=0)
+        matching.OWN_NORMS = True
+        _assert_same_bits(want, matching.match_l2(tq, tt, vq, vt, nq_, nt_, precision=1))
+    finally:
+        matching.OWN_NORMS = saved
