@@ -63,6 +63,10 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the batches alternate over: with 2, the latency-bound RANSAC stages of one batch "
                          "run beside the MFMA-bound matcher of the next")
+    ap.add_argument("--cu-split", type=int, default=0,
+                    help="experiment (VERDICT r2 item 7): every batch slot gets TWO streams created with CU masks — the matcher on "
+                         "256 - K CUs, the RANSAC tail on the other K — instead of one unmasked stream (0 = off; measured and "
+                         "dropped: profiles/r3/cu_split.txt)")
     ap.add_argument("--decompose", default="device", choices=["device", "host"],
                     help="where the winning E is decomposed into its (R, t) candidates: closed form on the device "
                          "(no host round trip) or NumPy SVD on the host")
@@ -309,13 +313,24 @@ def main():
                               kernel_events=kev[k] if state["timed"] else None)
         return (*r, "l2")
 
+    def split_match(slot):
+        """The matcher on the slot's matcher stream (its own CU partition), the caller's stream waits for it."""
+        tail, ms = torch.cuda.current_stream(), match_streams[slot]
+        ms.wait_stream(tail)
+        with torch.cuda.stream(ms):
+            r = match()
+        for t in r[:-1]:
+            t.record_stream(tail)
+        tail.wait_stream(ms)
+        return r
+
     def front(slot=0):
         if args.h2d:
             cur["buf"] = slot_bufs[slot]
             for k in keys:
                 cur["buf"][k].copy_(pinned[k], non_blocking=True)
         b = cur["buf"]
-        return pipeline.relative_pose_front(match, b["kp_q"], b["kp_t"], None, None, None, thr_sq,
+        return pipeline.relative_pose_front((lambda: split_match(slot)) if match_streams else match, b["kp_q"], b["kp_t"], None, None, None, thr_sq,
                                             n_samples=S, seed=max(state["step"], 0) + 1000,
                                             decompose=args.decompose, want_counts=True, refine=not args.no_refine)
 
@@ -328,7 +343,23 @@ def main():
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream()]
     main_stream = torch.cuda.current_stream()
-    for st in streams:
+    match_streams = None
+    if args.cu_split > 0:
+        # partitioned instead of shared CUs: stream pairs with complementary CU masks (hipExtStreamCreateWithCUMask)
+        K = args.cu_split
+        tail_bits = set(range(K))
+        def masked_stream(bits):
+            words = (ctypes.c_uint32 * 8)(*[sum(1 << (i % 32) for i in bits if i // 32 == w) for w in range(8)])
+            h = ctypes.c_void_p()
+            hev.hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+            rc = hev.hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words)
+            if rc != 0:
+                raise SystemExit(f"hipExtStreamCreateWithCUMask failed ({rc})")
+            return torch.cuda.ExternalStream(h.value, device=dev)
+        n_slots = max(args.streams, 1)
+        streams = [masked_stream(tail_bits) for _ in range(n_slots)]
+        match_streams = [masked_stream(set(range(256)) - tail_bits) for _ in range(n_slots)]
+    for st in streams + (match_streams or []):
         st.wait_stream(main_stream)
 
     def run(n_steps, timed, gather=False):
@@ -487,7 +518,7 @@ def main():
                        "features": N_FEAT, "dim": DIM, "hypotheses": real_per_pair, "hypothesis_slots": 10 * S,
                        "minimal_samples": S, "ratio": 0.75, "row_norms": "ph_row_sqnorm, two-pass" if (args.given_norms or args.precision == 0) else "inside the matcher call (one read of each table)", "matcher": "ph_match_l2_ratio (matching + ratio test, exact re-scores only where the approximate scores do not decide)" if fused else "ph_match_l2_top2 + ph_ratio_filter_l2", "threshold_px": THR_PX, "scoring": "bail-out",
                        "refine": "none" if args.no_refine else f"device LM, {pipeline.REFINE_ITERS} iterations, Sampson cost truncated at {pipeline.REFINE_TRUNC:g} x threshold",
-                       "streams": args.streams, "decompose": args.decompose,
+                       "streams": args.streams, "cu_split": args.cu_split or None, "decompose": args.decompose,
                        "inputs": "pinned host memory, copied over PCIe inside every step (NOT the headline)" if args.h2d else "resident in HBM",
                        "hypothesis_source": "generated in the timed region: Philox minimal samples of the pair's own matches -> device 5-point solver "
                                             "(10 slots per sample; `hypotheses` = mean number of REAL models per pair = sum of n_solutions)",

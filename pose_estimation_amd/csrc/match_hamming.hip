@@ -22,9 +22,6 @@
 
 #include "common.hpp"
 
-#ifndef PH_HAM_ABLATE
-#define PH_HAM_ABLATE 0
-#endif
 namespace {
 
 constexpr int kIdxBits = 22;                      // train rows per view < 2^22
@@ -175,16 +172,10 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     // group maximum and the second-largest score inside the best group.  The hit path of a scan is 26 instructions
     // instead of 64 (keys on all sixteen rows) or ~100 (per-row compare / select).
     auto scan = [&](const f32x16& acc, int ct, int t0) {
-#if PH_HAM_ABLATE & 2
-        if (t0 >= 0) { m1[ct] = fmaxf(m1[ct], acc[0]); return; }      // timing only: the scores are not looked at
-#endif
         float m4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) m4[g] = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
         if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])) > bound[ct]) == 0ull) return;
-#if PH_HAM_ABLATE & 1
-        if (t0 >= 0) { m1[ct] = fmaxf(m1[ct], m4[0]); return; }     // timing only: no top-2 upkeep
-#endif
         const float ka = m4[0] + kTopFrac, kb = m4[1] + 0.5f, kc = m4[2] + 0.25f, kd = m4[3];
         float k1 = fmaxf(ka, kb), k2 = fminf(ka, kb);
         k2 = __builtin_amdgcn_fmed3f(k1, k2, kc); k1 = fmaxf(k1, kc);
