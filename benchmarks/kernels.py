@@ -119,8 +119,13 @@ def main():
         Xc = X @ Rt.T + torch.from_numpy(-R @ np.array([0.5, 0, 0])).float().to(dev)
         x2, y2 = (Xc[..., 0] / Xc[..., 2]).contiguous(), (Xc[..., 1] / Xc[..., 2]).contiguous()
         med, best = timeit(lambda: triangulation.triangulate(P1, P2, x1, y1, x2, y2), args.iters)
-        report("triangulate_kernel", f"B={B} N={N} C=1", med, best, 28.0 * B * N, "B/s", HBM_PEAK,
-               {"bound": "hbm", "points_per_s": B * N / med})
+        # SURVEY.md §8d prices a point at ~300 FLOP = 150 fma-class lane-ops (4 x 4 DLT system, Jacobi) over 28 bytes; by bytes the
+        # kernel would be HBM-bound, in practice the Jacobi sweeps make it VALU-bound, so the VALU fraction is the
+        # one reported as `frac`; the byte fraction stays beside it
+        report("triangulate_kernel", f"B={B} N={N} C=1", med, best, 150.0 * B * N, "lane-ops/s", VALU_PEAK,
+               {"bound": "valu", "points_per_s": B * N / med, "hbm_frac": 28.0 * B * N / med / HBM_PEAK,
+                "note": "algorithmic 150 lane-ops per point (SURVEY.md §8d: ~300 FLOP); the kernel executes more (three one-sided Jacobi "
+                        "sweeps of a 4 x 4 system in registers)"})
 
 
 if __name__ == "__main__":

@@ -82,6 +82,9 @@ int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float* out, void*
  *                              ~11 candidate rows per query inside a proven error band, the contract's f32
  *                              chain re-ranks them (dim 128; dim 64 runs the f32 kernel).  Needs workspace.
  * d1sq/d2sq = squared distances of the best / second-best train row (+inf when absent).
+ * norm_q = norm_t = NULL (PH_PRECISION_F16_RERANK, dim 128 only; both or neither): the call computes the squared row norms itself, in
+ * the passes that read the two tables anyway (one read of each table instead of two; same outputs bit for bit) — for views that are
+ * matched once.  Views shared by many pairs should keep their ph_row_sqnorm norms and hand them in.  The workspace size is the same.
  * Descriptors must be finite.  A NaN or infinite element makes the neighbours of the queries and train rows it touches
  * unspecified (they may come back as PH_NO_INDEX, and the two algorithms may then differ): comparisons with NaN are
  * false, so such rows are simply never preferred — no launch fails and nothing is read or written out of bounds. */

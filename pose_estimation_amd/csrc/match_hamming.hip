@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
         const int tile0 = t_begin / kHSR;
         // Copies: scalar base + ONE constant per-lane offset (tid * 16), LDS destination in scalar registers; the tile loop is
         // unrolled over the three ring buffers so that every LDS read is register + immediate: no vector instruction stands
-        // between the barrier and a wave's first MFMA (match_l2_filter.hip, DESIGN.md §3a "ablation study").
+        // between the barrier and a wave's first MFMA (match_l2_filter.hip, DESIGN.md Appendix A.2 "ablation study").
         const unsigned wave_s = __builtin_amdgcn_readfirstlane(wave);
         const unsigned voff = (unsigned)tid * 16u;
         auto stage = [&](int it, int buf) {

@@ -18,7 +18,11 @@
 // lane), both of the exact top-2 rows have sA >= a2 - 2 e_i: such rows are appended to a candidate list.  Every
 // (query, train split, lane half) owns a private list segment and counts in a register, so an append is one
 // fire-and-forget store: no atomics, nothing to wait for.  A short priming pass over the first tiles sets the bound
-// before anything is appended, so a query collects ~11 candidates out of 8192 rows.  A list entry is (row, sA).
+// before anything is appended, and those tiles are seen again last, under the final bound, so a query collects ~8
+// candidates out of 8192 rows.  A list entry is (row, sA).
+// The scales need the row norms' maxima.  A caller that hands in ph_row_sqnorm's norms gets them from a reduction over
+// those (l2_filter_prep_kernel); with norm_q = norm_t = NULL the call computes the norms itself inside the passes that
+// read the two tables anyway, on provisional scales that are checked afterwards ("norms computed inside the call" below).
 //
 // Re-rank.  l2_rerank_kernel first prunes the list with the FINAL bound (second-largest listed sA - 2 e_i: 2-3 rows
 // survive), then evaluates the contract's exact chain (k order 8c+{0,4,1,5,2,6,3,7}, start
@@ -499,7 +503,8 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
             if (qw0 + ct * 32 + li < nqv) cnt[qoff[ct]] = kCapH + 1;
         return;
     }
-    const float resc_u = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(resc)));
+    const uint32_t resc_bits = __builtin_amdgcn_readfirstlane(__float_as_uint(resc));      // compared as an integer: a scalar compare
+    const float resc_u = __uint_as_float(resc_bits);
 
     const int t_begin = split * rows_per_split;          // a multiple of kSR
     const int t_end = min(ntv, t_begin + rows_per_split);
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
     // front — the k-step of one fp16 product is only kQT MFMAs long: too short to hide an LDS read issued one step ahead
     // — then its MFMA chains run back to back, then its scores are filtered): one tile's fragments and accumulators live
     // at a time keep the kernel at <= 168 VGPR, i.e. three blocks per CU (two cost 18 %, alone and with the other kernels
-    // of the step overlapping on other streams: profiles/r2/filter_ablation.txt, DESIGN.md §8).
+    // of the step overlapping on other streams: profiles/r2/filter_ablation.txt, DESIGN.md Appendix A.2).
     // The other lane half holds the same query (its other rows): the second-largest of the union of the two halves'
     // top-2 is the tighter bound — half of the time the best two rows sit in different halves.  Once per staged tile,
     // unconditionally (some lane of the wave has a hit in nearly every staged tile; thr is the same in both halves; a bound
@@ -572,7 +577,7 @@ __global__ __launch_bounds__(WAVES * 64, 3) void l2_filter_kernel(
             const float4 z = *(const float4*)(sm + (poff + (pbase + 32u * g)));     // rows 8g + 4h .. +3
             preset[4 * g + 0] = z.x; preset[4 * g + 1] = z.y; preset[4 * g + 2] = z.z; preset[4 * g + 3] = z.w;
         }
-        if (FN && resc_u != 1.0f) {                  // wave-uniform, rare: the image's presets carry the provisional query scale
+        if (FN && resc_bits != 0x3f800000u) {                  // wave-uniform, rare: the image's presets carry the provisional query scale
 #pragma unroll
             for (int r = 0; r < 16; ++r) preset[r] *= resc_u;
         }

@@ -13,9 +13,34 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 def _lines():
     out = []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_v1[0-9].json"))):
-        out.append((os.path.basename(f), json.loads(open(f).read().strip().splitlines()[-1])))
+    for pat in ("bench_v1[0-9].json", "bench_r3[a-z].json"):
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", pat))):
+            out.append((os.path.basename(f), json.loads(open(f).read().strip().splitlines()[-1])))
     return out
+
+
+def test_round3_lines_carry_every_baseline_config():
+    """configs[2..4], the single-pair latency and the f32-only rate are part of the ONE line, each
+    all-pairs / PnP entry with its own roofline and its pair count; traffic comes from a committed PMC summary."""
+    lines = [d for name, d in _lines() if name.startswith("bench_r3") and "other_configs" in d]
+    assert lines, "no committed round-3 bench line with other_configs"
+    d = lines[-1]
+    oc = d["other_configs"]
+    keys = list(oc)
+    for want in ("configs[2]", "configs[3] cfg4 binary", "configs[3] cfg4 f32", "configs[4]", "configs[1] literally", "f32_only_matcher"):
+        assert any(k.startswith(want) for k in keys), want
+    for k, v in oc.items():
+        if k.startswith(("configs[2]", "configs[3]")):
+            assert v["pairs"] >= (4950 if k.startswith("configs[2]") else 100000) and v["hypotheses"] >= 4096
+            assert v["ok_within_1deg"] > 0.99 and 0 < v["roofline"]["frac"] < 1
+        if k.startswith("configs[4]"):
+            assert [l["threshold_px"] for l in v] == [8.0, 2.0] and all(l["hypotheses"] >= 16384 and l["roofline"]["bound"] == "valu" for l in v)
+        if k.startswith("configs[1]"):
+            assert [l["pairs_per_batch"] for l in v] == [1, 8] and all(l["graph_table_equals_eager"] for l in v)
+    r = d["roofline"]
+    if r["traffic"] is not None:
+        assert "profiles/r3/" in r["traffic_source"] and os.path.exists(os.path.join(ROOT, r["traffic_source"].split(":")[0]))
+        assert 0.5 < r["traffic"] / (8.49e6 * d["config"]["pairs_per_step_per_gpu"]) < 1.5
 
 
 def test_committed_bench_lines_follow_the_contract():
