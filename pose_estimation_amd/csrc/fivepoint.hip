@@ -153,13 +153,13 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
         double n2 = 0.0;
 #pragma unroll
         for (int i = k; i < 9; ++i) n2 = fma(M[i][k], M[i][k], n2);
-        const double nrm = sqrt(n2);
+        const double nrm = n2 > 0.0 ? n2 * ph5::fast_rsqrt(n2) : 0.0;     // H_k is orthogonal whatever the last bits of |x| are
         ok &= nrm > 1e-12;                               // a column that is (numerically) dependent: degenerate sample
         const double alpha = M[k][k] > 0.0 ? -nrm : nrm;
         const double v0 = M[k][k] - alpha;
         M[k][k] = v0;
         const double vtv = fma(v0, v0, n2 - (v0 + alpha) * (v0 + alpha));     // |v|^2 = |x|^2 - x0^2 + v0^2
-        beta[k] = vtv > 0.0 ? 2.0 / vtv : 0.0;
+        beta[k] = vtv > 0.0 ? 2.0 * ph5::fast_rcp(vtv) : 0.0;
 #pragma unroll
         for (int j = k + 1; j < 5; ++j) {
             double d = 0.0;
@@ -247,28 +247,27 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
     int piv = (l < 10) ? -1 : 99;                        // pivot index this lane's row became (-1: not yet); idle lanes never compete
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
-        const double v = piv < 0 ? fabs(A[c]) : -1.0;
-        double best = -1.0;
-        int p = 0;
+        // arg-max of |A[c]| over the rows not used yet, on f32 copies (which of two nearly equal candidates becomes the
+        // pivot changes the result's rounding, nothing else): a key of the value's upper 28 bits over 15 - lane (ties ->
+        // the lowest lane), one 32-bit shuffle and one integer max per row instead of a 64-bit shuffle, a compare and three
+        // selects.  A row that is used up has key 0, below every candidate's.
+        const uint32_t key = piv < 0 ? ((__float_as_uint((float)fabs(A[c])) & ~15u) | (uint32_t)(15 - l)) : 0u;
+        uint32_t bk = 0u;
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            const double vk = __shfl(v, base + k);
-            if (vk > best) { best = vk; p = k; }
-        }
-        ok &= best > 1e-14;
+        for (int k = 0; k < kGroup; ++k) bk = max(bk, (uint32_t)__shfl((int)key, base + k));
+        const int p = 15 - (int)(bk & 15u);
+        ok &= __uint_as_float(bk & ~15u) > 1e-14f;       // false for a NaN too
         const bool me = (l == p);
+        double f = A[c];
         if (me) {
-            const double inv = 1.0 / A[c];
+            const double inv = ph5::fast_rcp(A[c]);
 #pragma unroll
             for (int j = c + 1; j < 20; ++j) A[j] *= inv;
             piv = c;
+            f = 0.0;                                     // the pivot row itself stays as it is
         }
-        const double f = A[c];
 #pragma unroll
-        for (int j = c + 1; j < 20; ++j) {
-            const double pr = __shfl(A[j], base + p);
-            A[j] = me ? A[j] : fma(-f, pr, A[j]);
-        }
+        for (int j = c + 1; j < 20; ++j) A[j] = fma(-f, __shfl(A[j], base + p), A[j]);
     }
     // ---- P7: the right halves of rows e..j (pivots 4..9) -> LDS, by pivot index
     if (piv >= 4 && piv < 10) {
@@ -342,6 +341,18 @@ __global__ __launch_bounds__(64) void fivepoint_poly_kernel(const float* __restr
     }
 }
 
+// Start values of the root iteration (fivepoint_core.hpp's aberth_start10: points on a circle of the geometric-mean
+// root radius) by the f32 hardware transcendentals: v_log / v_exp / v_sin / v_cos instead of f64 pow, sin and cos
+// (several hundred instructions).  Start values only have to be distinct and of the right magnitude.
+__device__ __forceinline__ ph5::cplx aberth_start_fast(const double (&c)[11], int n, int k) {
+    const double x = fmin(fmax(fabs(c[0] / ph5::lead_coeff(c, n)), 1e-30), 1e30);   // the radius is clamped to [1e-3, 1e3] anyway
+    const float inv_n = __builtin_amdgcn_rcpf((float)n);
+    float rad = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)x) * inv_n);
+    rad = fminf(fmaxf(rad, 1e-3f), 1e3f);
+    const float rev = (float)k * inv_n + 0.4f / 6.2831853f;                           // angle in revolutions
+    return {(double)(rad * __builtin_amdgcn_cosf(rev)), (double)(rad * __builtin_amdgcn_sinf(rev))};
+}
+
 // Stage 2: one lane per (sample, root): 6 samples x 10 roots per wave (lanes 60-63 idle).  The ten lanes
 // of a sample run the Aberth-Ehrlich iteration together (simultaneous update, roots exchanged by
 // shuffles), then every lane turns its own root into an essential matrix and writes slot k.
@@ -360,29 +371,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void
     const int n = Pp->n;
     double c[11];                                          // the polynomial in registers, zero above its degree
 #pragma unroll
-    for (int q = 0; q < 11; ++q) c[q] = (q <= n) ? Pp->c[q] : 0.0;
+    for (int q = 0; q < 11; ++q) c[q] = Pp->c[q];                                       // eleven plain loads, then selects: a
+#pragma unroll                                                                     // conditional load is a branch each
+    for (int q = 0; q < 11; ++q) c[q] = (q <= n) ? c[q] : 0.0;
     const bool live = active && k < n;
-    ph5::cplx z = live ? ph5::aberth_start10(c, n, k) : ph5::cplx{0.0, 0.0};
+    ph5::cplx z = live ? aberth_start_fast(c, n, k) : ph5::cplx{0.0, 0.0};
+    double tol = ph5::kAberthTol;
     for (int it = 0; it < ph5::kAberthMaxIter; ++it) {
-        ph5::cplx sum = {0.0, 0.0};
+        // The repulsion term sum_j 1/(z_k - z_j) in FLOAT32 (the roots are exchanged as f32 copies, one quarter-rate
+        // reciprocal per term): it only steers the iterates apart — the fixed points of the update are the zeros of p
+        // whatever the term is, p and p' stay in f64, and every root is polished on the real axis afterwards — and it
+        // was three quarters of an iteration in f64 (nine f64 reciprocals with two Newton steps each, 36 shuffles).
+        // The copies are clamped to +-1e18 (squares stay finite); a difference whose square is below the normal range
+        // contributes nothing.
+        const float zrf = fminf(fmaxf((float)z.re, -1e18f), 1e18f), zif = fminf(fmaxf((float)z.im, -1e18f), 1e18f);
+        float sre = 0.0f, sim = 0.0f;
 #pragma unroll
         for (int d = 1; d < 10; ++d) {
             int kk = k + d; kk = kk >= 10 ? kk - 10 : kk;
             const int src = base + kk;
-            const double zr = __shfl(z.re, src), zi = __shfl(z.im, src);
-            if (kk < n) {
-                const ph5::cplx dd = {z.re - zr, z.im - zi};
-                const ph5::cplx inv = ph5::cinv(dd);
-                sum.re += inv.re; sum.im += inv.im;
-            }
+            const float dr = zrf - __shfl(zrf, src), di = zif - __shfl(zif, src);
+            const float n2 = fmaf(dr, dr, di * di);
+            const float r = (kk < n && n2 > 1e-37f) ? __builtin_amdgcn_rcpf(n2) : 0.0f;
+            sre = fmaf(dr, r, sre); sim = fmaf(-di, r, sim);
         }
-        double change = 0.0;
+        const ph5::cplx sum = {(double)sre, (double)sim};
+        if (it >= 13 && (it - 13) % 3 == 0) tol *= 10.0;           // = ph5::aberth_tol(it)
+        bool settled = true;
         if (live) {
             const ph5::cplx w = ph5::aberth_step10(c, z, sum);
             z.re -= w.re; z.im -= w.im;
-            change = (fabs(w.re) + fabs(w.im)) / (fabs(z.re) + fabs(z.im) + 1e-30);
+            settled = fabs(w.re) + fabs(w.im) < tol * (fabs(z.re) + fabs(z.im) + 1e-30);    // relative change of this root
         }
-        if (__all(change < ph5::aberth_tol(it))) break;            // wave-uniform exit
+        if (__all(settled)) break;                                 // wave-uniform exit
     }
     float e9[9];
     bool real = false;

@@ -48,6 +48,17 @@ PH_HD inline double fast_rcp(double x) {
     return 1.0 / x;
 #endif
 }
+// 1/sqrt(x) the same way: v_rsq_f64 and two Newton steps
+PH_HD inline double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
 PH_HD inline cplx cinv(cplx b) {                       // 1/b with ONE real reciprocal
     const double r = fast_rcp(b.re * b.re + b.im * b.im);
     return {b.re * r, -b.im * r};
@@ -311,12 +322,6 @@ PH_HD inline double lead_coeff(const double (&c)[11], int n) {
     for (int k = 1; k <= 10; ++k) l = (k == n) ? c[k] : l;
     return l;
 }
-PH_HD inline cplx aberth_start10(const double (&c)[11], int n, int k) {
-    double rad = pow(fabs(c[0] / lead_coeff(c, n)) + 1e-300, 1.0 / n);
-    rad = fmin(fmax(rad, 1e-3), 1e3);
-    const double a = 6.283185307179586 * k / n + 0.4;
-    return {rad * cos(a), rad * sin(a)};
-}
 PH_HD inline cplx aberth_step10(const double (&c)[11], cplx zk, cplx sum) {
     // p(z) and p'(z) of a REAL polynomial at a complex point by synthetic division with the real quadratic
     // x^2 - r x + s (r = 2 Re z, s = |z|^2) that has z as a root: two real fmas per coefficient instead of a complex
@@ -353,7 +358,7 @@ PH_HD inline bool root_to_E10(const double (&c)[11], const Poly5& P, cplx z, flo
         double p = c[10], dp = 0.0;
 #pragma unroll
         for (int j = 9; j >= 0; --j) { dp = dp * zr + p; p = p * zr + c[j]; }
-        if (dp != 0.0) zr -= p / dp;
+        if (dp != 0.0) zr -= p * fast_rcp(dp);          // a Newton step forgives its quotient's last bits
     }
     {   // a complex pair with a tiny imaginary part is not a solution: require p(zr) = 0 to rounding
         double p = c[10], mag = fabs(c[10]);
@@ -378,8 +383,8 @@ PH_HD inline bool root_to_E10(const double (&c)[11], const Poly5& P, cplx z, flo
         const double nn = w0 * w0 + w1 * w1 + w2 * w2;
         if (nn > vbest) { vbest = nn; v0 = w0; v1 = w1; v2 = w2; }
     }
-    if (!(fabs(v2) > 1e-14 * sqrt(vbest))) return false;
-    const double xr = v0 / v2, yr = v1 / v2;
+    if (!(v2 * v2 > 1e-28 * vbest)) return false;          // |v2| > 1e-14 |v|
+    const double rv = fast_rcp(v2), xr = v0 * rv, yr = v1 * rv;
     double E[9], n2 = 0.0;
 #pragma unroll
     for (int e = 0; e < 9; ++e) {
@@ -387,7 +392,7 @@ PH_HD inline bool root_to_E10(const double (&c)[11], const Poly5& P, cplx z, flo
         n2 += E[e] * E[e];
     }
     if (!(n2 > 0.0) || !(n2 < HUGE_VAL)) return false;
-    const double inv = 1.0 / sqrt(n2);
+    const double inv = fast_rsqrt(n2);                     // the result is stored as f32
 #pragma unroll
     for (int e = 0; e < 9; ++e) e9[e] = (float)(E[e] * inv);
     return true;
