@@ -5,24 +5,58 @@
 //   minimise  sum_i min(r_i^2, c^2),  r_i = (x2' E x1) / sqrt((Ex1)_0^2 + (Ex1)_1^2 + (E'x2)_0^2 + (E'x2)_1^2),
 //   E = [t]x R, |t| = 1: 5 degrees of freedom, R <- exp([dw]x) R, t <- normalise(t + d3 b1 + d4 b2).
 //
-// One 512-thread block per pair, float64.  A pass over the pair's correspondences (coalesced SoA loads, points on
-// lanes) produces the normal equations of the correspondences inside the truncation (15 + 5 sums), their sum of
-// squares, their number and the number of valid correspondences; the sums are reduced by wave shuffles and an 8-row
-// LDS table; thread 0 solves the damped 5x5 system (Cholesky, Marquardt scaling) and proposes the next pose, whose
-// pass is both its cost and — when it is accepted — the next normal equations: ONE pass per iteration.
+// One 512-thread block per pair.  A pass over the pair's correspondences (coalesced SoA loads, points on lanes) produces the
+// normal equations of the correspondences inside the truncation (15 + 5 sums), their sum of squares, their number and the
+// number of valid correspondences — residuals and cost in float64, Jacobian rows and normal equations in float32 (see
+// `pass`); the sums are reduced by DPP adds inside a wave and an 8-row LDS table; thread 0 solves the damped 5x5 system in
+// float64 (Cholesky, Marquardt scaling) and proposes the next pose, whose pass is both its cost and — when it is
+// accepted — the next normal equations: ONE pass per iteration.  57 us for 64 pairs x 4 900 matches x 5 passes (85 us with
+// everything in f64, shuffles for the sums and IEEE divisions in the solve: the pass is bound by instruction issue on the
+// pair's one CU, 2 waves per SIMD).
 #include <math.h>
 
 #include "common.hpp"
 
 namespace {
 
-constexpr int kNT = 512;          // 8 waves: two per SIMD of one CU, up to 256 VGPRs each (the 5 derivative matrices stay in registers)
+constexpr int kNT = 512;          // 8 waves: two per SIMD of one CU (the 5 derivative matrices stay in registers)
 constexpr int kNW = kNT / 64;
 constexpr int kSums = 23;          // 15 (J'J upper) + 5 (J'r) + ssq + n_inside + n_valid
+
+// 1/x and 1/sqrt(x) for thread 0's serial algebra: the hardware estimate (about 2^-27) and two Newton steps, ~7 dependent
+// instructions instead of the ~30 of an IEEE-correct f64 division or square root (a damped LM step forgives its last bit).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    return r * fma(-0.5 * x * r, r, 1.5);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Sum over the wave by DPP adds (data-parallel primitives: the cross-lane move rides on the v_add_f32 itself — six vector
+// instructions, nothing through the LDS pipe; six ds_bpermute round trips per sum, 23 sums per pass, were 4.6 us of a
+// 15 us LM iteration).  The total is valid in LANE 63 only.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    // lanes whose source is outside the row mask / invalid add 0 (bound_ctrl: out-of-range sources read as 0)
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f63(float v) {
+    v = dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);     // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a row of 16 holds the row's sum
+    v = dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3: lane 63 = the wave's sum
     return v;
 }
 
@@ -42,7 +76,7 @@ __device__ __forceinline__ void tangent_basis(const double* t, double* b1, doubl
     if (a == 0) { b1[0] = 0.0; b1[1] = t[2]; b1[2] = -t[1]; }
     else if (a == 1) { b1[0] = -t[2]; b1[1] = 0.0; b1[2] = t[0]; }
     else { b1[0] = t[1]; b1[1] = -t[0]; b1[2] = 0.0; }
-    const double n = 1.0 / sqrt(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
+    const double n = fast_rsqrt(b1[0] * b1[0] + b1[1] * b1[1] + b1[2] * b1[2]);
     b1[0] *= n; b1[1] *= n; b1[2] *= n;
     b2[0] = t[1] * b1[2] - t[2] * b1[1];
     b2[1] = t[2] * b1[0] - t[0] * b1[2];
@@ -51,10 +85,20 @@ __device__ __forceinline__ void tangent_basis(const double* t, double* b1, doubl
 
 __device__ __forceinline__ void exp_so3(const double* w, double (&R)[9]) {
     const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-    const double th = sqrt(th2);
-    double a, b;                                   // R = I + a [w]x + b [w]x^2
-    if (th < 1e-12) { a = 1.0; b = 0.0; }
-    else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+    double a, b;                                   // R = I + a [w]x + b [w]x^2, a = sin(th)/th, b = (1 - cos(th))/th^2
+    if (th2 < 0.25) {                              // an LM step: the two series to th^18 (below 1e-17 relative at th = 0.5)
+        a = 1.0; b = 0.5;
+        double ta = 1.0, tb = 0.5;
+#pragma unroll
+        for (int k = 1; k <= 9; ++k) {
+            ta *= th2 * (-1.0 / (double)((2 * k) * (2 * k + 1)));          // constant factors: multiplications
+            tb *= th2 * (-1.0 / (double)((2 * k + 1) * (2 * k + 2)));
+            a += ta; b += tb;
+        }
+    } else {
+        const double th = sqrt(th2);
+        a = sin(th) / th; b = (1.0 - cos(th)) / th2;
+    }
     const double x = w[0], y = w[1], z = w[2];
     R[0] = 1.0 - b * (y * y + z * z); R[1] = -a * z + b * x * y;        R[2] = a * y + b * x * z;
     R[3] = a * z + b * x * y;         R[4] = 1.0 - b * (x * x + z * z); R[5] = -a * x + b * y * z;
@@ -89,50 +133,98 @@ __device__ __forceinline__ void pass(const double* Rsh, const double* tsh, const
         skew_mul(b1, R, G[3]);
         skew_mul(b2, R, G[4]);
     }
-    double acc[kSums];
+    // Precision split: the residual r = num / sqrt(den) and the cost are float64 (num is a sum of O(1) terms that cancel to
+    // 1e-4: f32 would leave r three digits, and accept / reject compares costs to 1e-9); the Jacobian row and the normal
+    // equations are float32 (half the issue cycles of f64 on this chip): a Gauss-Newton step tolerates a 1e-6 relative error of
+    // J, and the stationary point it moves by is |dJ| |r| / |J|^2 ~ 1e-10 rad.  Per-thread partial sums (<= N / 512 terms)
+    // and the wave reduction run in f32, the eight waves' sums are added in f64 by thread 0.
+    float Gf[5][9];
 #pragma unroll
-    for (int k = 0; k < kSums; ++k) acc[k] = 0.0;
-    for (int i0 = 0; i0 < nv; i0 += kNT) {
-        const int i = i0 + tid;
-        bool on = i < nv;
-        if (on && mask) on = (mask[i >> 6] >> (i & 63)) & 1ull;
-        if (!on) continue;
-        const double a1 = x1[i], c1 = y1[i], a2 = x2[i], c2 = y2[i];
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Gf[q][k] = (float)G[q][k];
+    float accf[20];
+    double ssq = 0.0;
+    float n_in = 0.0f, n_all = 0.0f;                      // counts <= N < 2^24: exact
+#pragma unroll
+    for (int k = 0; k < 20; ++k) accf[k] = 0.0f;
+    auto point = [&](float a1f, float c1f, float a2f, float c2f) {
+        const double a1 = a1f, c1 = c1f, a2 = a2f, c2 = c2f;
         const double e0 = E[0] * a1 + E[1] * c1 + E[2], e1 = E[3] * a1 + E[4] * c1 + E[5], e2 = E[6] * a1 + E[7] * c1 + E[8];
         const double f0 = E[0] * a2 + E[3] * c2 + E[6], f1 = E[1] * a2 + E[4] * c2 + E[7];
         const double num = a2 * e0 + c2 * e1 + e2;
         const double den = fmax(e0 * e0 + e1 * e1 + f0 * f0 + f1 * f1, 1e-300);
-        // 1/sqrt(den): f32 estimate + two Newton steps (23 -> 46 -> 92 bits) instead of an f64 sqrt and an f64 division
+        // 1/sqrt(den): the f32 estimate (23 bits) + one f64 Newton step (46 bits) instead of an f64 sqrt and an f64 division
         double isq = (double)__builtin_amdgcn_rsqf((float)den);
         isq = isq * (1.5 - 0.5 * den * isq * isq);
-        isq = isq * (1.5 - 0.5 * den * isq * isq);
-        const double iden = isq * isq;
         const double r = num * isq;
-        acc[22] += 1.0;
-        if (!(r * r < c_sq)) continue;
-        double J[5];
+        n_all += 1.0f;
+        if (!(r * r < c_sq)) return;
+        ssq += r * r;
+        n_in += 1.0f;
+        // d r / d p_k = (x2' G_k x1) / sqrt(den) - num (e . (G_k x1) + f . (G_k' x2)) / den^1.5 (first two components) is linear
+        // in G_k:  J_k = G_k : W,  W_ij = u_j (v_i / sqrt(den) - cf e_i) - cf v_i f_j,  u = (x1, 1), v = (x2, 1), e_2 = f_2 = 0 —
+        // W once per correspondence (16 instructions), then nine fmas per parameter instead of nineteen.
+        const float isqf = (float)isq, rf = (float)r;
+        const float cf = rf * isqf * isqf;                 // num / den^1.5
+        const float p0 = a2f * isqf - cf * (float)e0, p1 = c2f * isqf - cf * (float)e1, p2 = isqf;
+        const float q0 = cf * (float)f0, q1 = cf * (float)f1;
+        const float W[9] = {p0 * a1f - a2f * q0, p0 * c1f - a2f * q1, p0,
+                            p1 * a1f - c2f * q0, p1 * c1f - c2f * q1, p1,
+                            p2 * a1f - q0,       p2 * c1f - q1,       p2};
+        float J[5];
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const double* g = G[k];
-            const double g0 = g[0] * a1 + g[1] * c1 + g[2], g1 = g[3] * a1 + g[4] * c1 + g[5], g2 = g[6] * a1 + g[7] * c1 + g[8];
-            const double h0 = g[0] * a2 + g[3] * c2 + g[6], h1 = g[1] * a2 + g[4] * c2 + g[7];
-            const double dnum = a2 * g0 + c2 * g1 + g2;
-            const double dden = 2.0 * (e0 * g0 + e1 * g1 + f0 * h0 + f1 * h1);
-            J[k] = dnum * isq - 0.5 * num * dden * isq * iden;
+            float j = Gf[k][0] * W[0];
+#pragma unroll
+            for (int e = 1; e < 9; ++e) j += Gf[k][e] * W[e];
+            J[k] = j;
         }
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
-            for (int c = a; c < 5; ++c) acc[q++] += J[a] * J[c];
+            for (int c = a; c < 5; ++c) { accf[q] += J[a] * J[c]; ++q; }
 #pragma unroll
-        for (int a = 0; a < 5; ++a) acc[15 + a] += J[a] * r;
-        acc[20] += r * r;
-        acc[21] += 1.0;
+        for (int a = 0; a < 5; ++a) accf[15 + a] += J[a] * rf;
+    };
+    // The correspondences come from the L2 (the pair's four arrays, read again by every pass); the next trip's loads are issued
+    // before this trip's arithmetic.  (Groups of 2 or 4 trips per round of loads: 73 / 78 us against 71 — the pass is bound by
+    // instruction issue, not by these loads — and 16 resident correspondences per thread spill.)
+    constexpr int kGrp = 1;
+    float nx[kGrp][4];
+    uint32_t nbits = 0u;
+    auto fetch = [&](int i0) {
+        nbits = 0u;
+#pragma unroll
+        for (int u = 0; u < kGrp; ++u) {
+            const int i = i0 + u * kNT + tid;
+            const bool in = i < nv;
+            const uint64_t w = (in && mask) ? mask[i >> 6] : ~0ull;
+            nx[u][0] = in ? x1[i] : 0.0f; nx[u][1] = in ? y1[i] : 0.0f; nx[u][2] = in ? x2[i] : 0.0f; nx[u][3] = in ? y2[i] : 0.0f;
+            nbits |= (uint32_t)(in && ((w >> (i & 63)) & 1ull)) << u;
+        }
+    };
+    if (nv > 0) fetch(0);
+    for (int i0 = 0; i0 < nv; i0 += kGrp * kNT) {
+        float cur[kGrp][4];
+        const uint32_t bits = nbits;
+#pragma unroll
+        for (int u = 0; u < kGrp; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[u][k] = nx[u][k];
+        if (i0 + kGrp * kNT < nv) fetch(i0 + kGrp * kNT);
+#pragma unroll
+        for (int u = 0; u < kGrp; ++u)
+            if ((bits >> u) & 1u) point(cur[u][0], cur[u][1], cur[u][2], cur[u][3]);
     }
+    double acc[kSums];
 #pragma unroll
-    for (int k = 0; k < kSums; ++k) acc[k] = wave_sum(acc[k]);
-    if (lane == 0)
+    for (int k = 0; k < 20; ++k) acc[k] = (double)wave_sum_f63(accf[k]);
+    acc[20] = wave_sum(ssq);                              // the one f64 sum: by shuffles, valid in every lane
+    acc[21] = (double)wave_sum_f63(n_in);
+    acc[22] = (double)wave_sum_f63(n_all);
+    if (lane == 63)
 #pragma unroll
         for (int k = 0; k < kSums; ++k) red[wave][k] = acc[k];
     __syncthreads();
@@ -218,6 +310,8 @@ __global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* 
                 }
 #pragma unroll
                 for (int a = 0; a < 5; ++a) M[a][a] += lambda * M[a][a] + 1e-300;
+                // Cholesky with the reciprocals of the diagonal (one rsqrt per pivot, no division anywhere)
+                double rd[5];
                 bool ok = true;
 #pragma unroll
                 for (int a = 0; a < 5; ++a)
@@ -226,8 +320,8 @@ __global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* 
                         double v = M[a][c];
 #pragma unroll
                         for (int k = 0; k < c; ++k) v -= L[a][k] * L[c][k];
-                        if (a == c) { ok = ok && (v > 0.0); L[a][a] = sqrt(fmax(v, 1e-300)); }
-                        else L[a][c] = v / L[c][c];
+                        if (a == c) { ok = ok && (v > 0.0); rd[a] = fast_rsqrt(fmax(v, 1e-300)); }
+                        else L[a][c] = v * rd[c];
                     }
                 if (!ok) {
                     lambda *= 10.0;
@@ -239,14 +333,14 @@ __global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* 
                     double v = -sh_g[a];
 #pragma unroll
                     for (int k = 0; k < a; ++k) v -= L[a][k] * d[k];
-                    d[a] = v / L[a][a];
+                    d[a] = v * rd[a];
                 }
 #pragma unroll
                 for (int a = 4; a >= 0; --a) {
                     double v = d[a];
 #pragma unroll
                     for (int k = a + 1; k < 5; ++k) v -= L[k][a] * d[k];
-                    d[a] = v / L[a][a];
+                    d[a] = v * rd[a];
                 }
                 double dR[9], Rcur[9], b1[3], b2[3], tcur[3];
                 exp_so3(d, dR);
@@ -263,7 +357,7 @@ __global__ __launch_bounds__(kNT) void refine_relative_pose_kernel(const float* 
                 double tn[3], n2 = 0.0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { tn[k] = tcur[k] + d[3] * b1[k] + d[4] * b2[k]; n2 += tn[k] * tn[k]; }
-                const double inv = 1.0 / sqrt(n2);
+                const double inv = fast_rsqrt(n2);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) sh_tc[k] = tn[k] * inv;
                 dd = 0.0;
