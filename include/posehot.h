@@ -289,6 +289,14 @@ int ph_gather_models(const float* models, const int32_t* sel, int B, int H, int 
  * No reference counterpart (glue of north_star's RANSAC). */
 int ph_compact_models(const float* models, int B, int H, int stride, float* out, int32_t* slot, int32_t* n_live,
                       void* stream);
+/* The same with the number of live models of every group of `group` consecutive slots given: counts [B][H / group] (what
+ * the solvers report as n_solutions: group = 10 for ph_solve_essential_5pt, 4 for ph_solve_p3p; H a multiple of group).
+ * The counts place the pieces an item is cut into, so many blocks work on one item (14 us instead of 27 for 64 x 9 200 x 9
+ * floats); which slots are live is still read from the models.  PRECONDITION: counts[b][g] equals the number of non-zero
+ * models among slots g*group .. g*group + group - 1 (otherwise the output has gaps or overlaps; nothing is written outside
+ * the item).  Outputs as ph_compact_models.  Shapes other than (stride 9, group 10) and (12, 4) take ph_compact_models. */
+int ph_compact_models_counted(const float* models, const int32_t* counts, int group, int B, int H, int stride,
+                              float* out, int32_t* slot, int32_t* n_live, void* stream);
 int ph_lookup_index(const int32_t* table, const int32_t* sel, int B, int H, int32_t* out, void* stream);
 /* ph_decompose_essential: the recoverPose-style decomposition of hypothesis sel[b] (NULL = 0) of every item's
  * [H][9] block of essential matrices into its four (R, t) candidates, on the device (closed form, float64; no

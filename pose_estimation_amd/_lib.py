@@ -53,6 +53,7 @@ SIGNATURES = {
     "ph_solve_essential_5pt_noalloc": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "ph_gather_models": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "ph_compact_models": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "ph_compact_models_counted": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "ph_lookup_index": (_i, [_p, _p, _i, _i, _p, _p]),
     "ph_decompose_essential": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ph_pose_table": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p]),

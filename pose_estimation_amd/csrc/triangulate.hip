@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
     }
 }
 
-// stable compaction of kept matches, one 256-thread block per pair.
+// Stable compaction of kept matches: a 256-thread block per 1024 queries of a pair (grid (chunks, B): a block per PAIR
+// walked 8 192 queries in four dependent rounds — 24 us for 64 pairs, on 64 of the 256 CUs).  A block first counts the
+// kept matches in front of its chunk (coalesced sweep over idx / keep: at most 64 KB from the L2), then packs its own.
 __global__ __launch_bounds__(256) void compact_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ keep,
                                                      const float2* __restrict__ kp_q, const float2* __restrict__ kp_t,
                                                      const int32_t* __restrict__ view_q, const int32_t* __restrict__ view_t,
@@ -137,54 +139,63 @@ __global__ __launch_bounds__(256) void compact_kernel(const int32_t* __restrict_
                                                      float* __restrict__ x2, float* __restrict__ y2,
                                                      int32_t* __restrict__ match_q, int32_t* __restrict__ match_t,
                                                      int32_t* __restrict__ n_match) {
-    // 2048 candidates per round, element i0 + 256 u + tid with thread tid in step u: the eight loads of a thread travel
-    // together, so a round costs two memory round trips and two barriers instead of sixteen of each.
-    constexpr int U = 8;
+    constexpr int U = 4;                                   // chunk = 256 * U queries, element i0 + 256 u + tid on thread tid
     __shared__ int wave_tot[U][4];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int red[4];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int vq = view_q ? view_q[b] : b, vt = view_t ? view_t[b] : b;
     const float2* KQ = kp_q + (size_t)vq * nq;
     const float2* KT = kp_t + (size_t)vt * nt;
-    int base = 0;
-    for (int i0 = 0; i0 < nq; i0 += 256 * U) {
-        int j[U], kp[U];
+    const int32_t* IDX = idx + (size_t)b * nq;
+    const int32_t* KEEP = keep + (size_t)b * nq;
+    const int i0 = c * (256 * U);
+    // this chunk's candidates first (their loads travel with the sweep's)
+    int j[U], kp[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 256 * u + tid;
-            j[u] = PH_NO_INDEX; kp[u] = 0;
-            if (i < nq) { j[u] = idx[(size_t)b * nq + i]; kp[u] = keep[(size_t)b * nq + i]; }
-        }
-        bool k[U];
-        int before[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            k[u] = kp[u] != 0 && j[u] >= 0 && j[u] < nt;
-            const unsigned long long bal = __ballot(k[u]);
-            before[u] = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wave_tot[u][wave] = __popcll(bal);
-        }
-        __syncthreads();
-        float2 a[U], t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k[u]) { a[u] = KQ[i0 + 256 * u + tid]; t[u] = KT[j[u]]; }
-        int off = base;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int mine = off;
-            for (int w = 0; w < wave; ++w) mine += wave_tot[u][w];
-            if (k[u]) {
-                const size_t o = (size_t)b * nq + mine + before[u];
-                x1[o] = a[u].x; y1[o] = a[u].y; x2[o] = t[u].x; y2[o] = t[u].y;
-                if (match_q) match_q[o] = i0 + 256 * u + tid;
-                if (match_t) match_t[o] = j[u];
-            }
-            off += wave_tot[u][0] + wave_tot[u][1] + wave_tot[u][2] + wave_tot[u][3];
-        }
-        base = off;
-        __syncthreads();
+    for (int u = 0; u < U; ++u) {
+        const int i = i0 + 256 * u + tid;
+        j[u] = PH_NO_INDEX; kp[u] = 0;
+        if (i < nq) { j[u] = IDX[i]; kp[u] = KEEP[i]; }
     }
-    if (tid == 0) n_match[b] = base;
+    int before = 0;
+    for (int i = tid; i < i0; i += 256 * 4) {              // i0 is a multiple of 1024: four loads per array in flight, no tail
+        int jj[4], kk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { jj[u] = IDX[i + 256 * u]; kk[u] = KEEP[i + 256 * u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) before += (kk[u] != 0 && jj[u] >= 0 && jj[u] < nt) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    bool k[U];
+    int rank[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        k[u] = kp[u] != 0 && j[u] >= 0 && j[u] < nt;
+        const unsigned long long bal = __ballot(k[u]);
+        rank[u] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[u][wave] = __popcll(bal);
+    }
+    if (lane == 0) red[wave] = before;
+    __syncthreads();
+    float2 a[U], t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (k[u]) { a[u] = KQ[i0 + 256 * u + tid]; t[u] = KT[j[u]]; }
+    int off = red[0] + red[1] + red[2] + red[3];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        int mine = off;
+        for (int w = 0; w < wave; ++w) mine += wave_tot[u][w];
+        if (k[u]) {
+            const size_t o = (size_t)b * nq + mine + rank[u];
+            x1[o] = a[u].x; y1[o] = a[u].y; x2[o] = t[u].x; y2[o] = t[u].y;
+            if (match_q) match_q[o] = i0 + 256 * u + tid;
+            if (match_t) match_t[o] = j[u];
+        }
+        off += wave_tot[u][0] + wave_tot[u][1] + wave_tot[u][2] + wave_tot[u][3];
+    }
+    if (c == (int)gridDim.x - 1 && tid == 0) n_match[b] = off;      // the last chunk's block has seen every kept match
 }
 
 // models[b][sel[b]][0..stride) -> out[b][0..stride): the winning hypothesis of every item in one small launch
@@ -199,35 +210,45 @@ __global__ __launch_bounds__(256) void gather_models_kernel(const float* __restr
 
 // Stable compaction of the non-empty models of every item (the solvers leave a slot all-zero when its root is not a
 // solution: 53 % of the 5-point slots, 55 % of the P3P slots): live models first, in slot order, the tail zero-filled,
-// plus the map compact position -> slot.  One 1024-thread block per item.
-// One 1024-thread block per item.  Per round of 65536 slots (one round for every shape of the pipelines): (1) slot h on
-// thread h mod 1024, the waves' ballots go to a table of 64-bit words; (2) wave 0 turns the table into exclusive prefix
-// counts; (3) every live slot is copied to base + prefix of its word + rank inside the word.  STRIDE = floats per model
-// when known at compile time (9, 12: the loads of a model are issued together instead of one round trip per float), 0 =
-// the run-time value.  29 us for 64 items x 9200 slots x 9 floats (39 us with a barrier-separated prefix per 1024 slots
-// and run-time stride); staging the models through LDS for fully coalesced accesses was slower (35 us), and so was
-// giving a thread 9 consecutive slots (98 us): what is left is the latency of 64 blocks walking 18 dependent rounds.
+// plus the map compact position -> slot.  One 1024-thread block per item, rounds of 1024 * U slots (one round for the
+// headline's 9 200 slots): (1) thread t loads slots t, t + 1024, ... of the round — all U * STRIDE loads in flight together —
+// and KEEPS them in registers; the waves' ballots go to a table of 64-bit words; (2) wave 0 turns the table into exclusive
+// prefix counts; (3) every live slot is written from the registers to base + prefix of its word + rank inside the word.
+// STRIDE = floats per model when known at compile time (9, 12), 0 = the run-time value (one slot per thread and round, read
+// twice).  One memory round trip and two barriers per round: 64 items x 9 200 slots x 9 floats take 27.5 us (30 with 1 024
+// slots per round and every model read for the ballot and again for the copy) — what is left is one CU per item moving
+// 660 KB in 36-byte pieces; ph_compact_models_counted below cuts an item over many blocks.
 template <int STRIDE>
 __global__ __launch_bounds__(1024) void compact_models_kernel(const float* __restrict__ models, int H, int stride_rt,
                                                              float* __restrict__ out, int32_t* __restrict__ slot,
                                                              int32_t* __restrict__ n_live) {
     const int stride = STRIDE > 0 ? STRIDE : stride_rt;
-    constexpr int kUnroll = STRIDE > 0 ? STRIDE : 1;
-    __shared__ unsigned long long mask[1024];
-    __shared__ int pref[1024];
+    constexpr int NE = STRIDE > 0 ? STRIDE : 1;            // floats held per slot
+    constexpr int U = STRIDE == 0 ? 1 : (STRIDE <= 9 ? 9 : 8);      // slots per thread and round: <= 96 registers of models
+    constexpr int kRound = 1024 * U;
+    __shared__ unsigned long long mask[kRound / 64];
+    __shared__ int pref[kRound / 64];
     __shared__ int total_sh;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* M = models + (size_t)b * H * stride;
     float* O = out + (size_t)b * H * stride;
     int32_t* S = slot + (size_t)b * H;
     int base = 0;                                          // live models before this round (the same in every thread)
-    for (int h0 = 0; h0 < H; h0 += 65536) {
-        const int span = min(H - h0, 65536), nw = (span + 63) / 64;
-        for (int r = tid; r < nw * 64; r += 1024) {
+    for (int h0 = 0; h0 < H; h0 += kRound) {
+        const int span = min(H - h0, kRound), nw = (span + 63) / 64;
+        float m[U][NE];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = u * 1024 + tid;
+            if ((r >> 6) >= nw) break;                     // wave-uniform: whole waves vote
             uint32_t any = 0;
             if (r < span) {
-#pragma unroll kUnroll
-                for (int e = 0; e < stride; ++e) any |= __float_as_uint(M[(size_t)(h0 + r) * stride + e]) << 1;      // +-0 -> 0
+                if (STRIDE > 0) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) { m[u][e] = M[(size_t)(h0 + r) * stride + e]; any |= __float_as_uint(m[u][e]) << 1; }   // +-0 -> 0
+                } else {
+                    for (int e = 0; e < stride; ++e) any |= __float_as_uint(M[(size_t)(h0 + r) * stride + e]) << 1;
+                }
             }
             const unsigned long long votes = __ballot(any != 0u);
             if (lane == 0) mask[r >> 6] = votes;
@@ -246,12 +267,19 @@ __global__ __launch_bounds__(1024) void compact_models_kernel(const float* __res
             if (lane == 63) total_sh = incl;
         }
         __syncthreads();
-        for (int r = tid; r < nw * 64; r += 1024) {
-            const unsigned long long m = mask[r >> 6];
-            if ((m >> lane) & 1ull) {
-                const int pos = base + pref[r >> 6] + __popcll(m & ((1ull << lane) - 1ull));
-#pragma unroll kUnroll
-                for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = M[(size_t)(h0 + r) * stride + e];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = u * 1024 + tid;
+            if ((r >> 6) >= nw) break;
+            const unsigned long long w = mask[r >> 6];
+            if ((w >> lane) & 1ull) {
+                const int pos = base + pref[r >> 6] + __popcll(w & ((1ull << lane) - 1ull));
+                if (STRIDE > 0) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) O[(size_t)pos * stride + e] = m[u][e];
+                } else {
+                    for (int e = 0; e < stride; ++e) O[(size_t)pos * stride + e] = M[(size_t)(h0 + r) * stride + e];
+                }
                 S[pos] = h0 + r;
             }
         }
@@ -263,6 +291,87 @@ __global__ __launch_bounds__(1024) void compact_models_kernel(const float* __res
         S[pos] = -1;
     }
     if (tid == 0) n_live[b] = base;
+}
+
+// The same compaction when the number of live models of every GROUP of `group` consecutive slots is known (the solvers
+// report it: n_solutions per minimal sample, 10 slots for the 5-point solver, 4 for P3P): the position of a chunk's first
+// live model is a sum over the counts in front of it — a few hundred integers — instead of a pass over the models in front
+// of it, so an item is cut into chunks of kChunkGroups * group slots with a block each: (chunks, B) blocks instead of B.
+// 64 items x 9 200 slots x 9 floats: 14 us against the one-block-per-item kernel's 27 (whose 64 blocks each move 660 KB through
+// one CU's memory path in 36-byte pieces).  Which slots of a chunk are live is still read from the models themselves; the
+// counts only place the chunk (a count that disagrees with its group's models leaves a gap or an overlap: precondition).
+constexpr int kCountedThreads = 256;
+template <int STRIDE, int GROUP>
+__global__ __launch_bounds__(kCountedThreads) void compact_models_counted_kernel(const float* __restrict__ models,
+                                                                                 const int32_t* __restrict__ counts, int H,
+                                                                                 float* __restrict__ out, int32_t* __restrict__ slot,
+                                                                                 int32_t* __restrict__ n_live) {
+    constexpr int kChunk = 1280;                           // slots per block: a multiple of 64, of 10 and of 4
+    static_assert(kChunk % 64 == 0 && kChunk % GROUP == 0 && kChunk % kCountedThreads == 0, "chunk");
+    constexpr int U = kChunk / kCountedThreads, kWords = kChunk / 64;
+    __shared__ unsigned long long mask[kWords];
+    __shared__ int pref[kWords];
+    __shared__ int red[2][kCountedThreads / 64];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h0 = c * kChunk, span = min(H - h0, kChunk), nw = (span + 63) / 64;
+    const float* M = models + (size_t)b * H * STRIDE;
+    float* O = out + (size_t)b * H * STRIDE;
+    int32_t* S = slot + (size_t)b * H;
+    // the chunk's models: all loads in flight together, kept in registers
+    float m[U][STRIDE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int r = u * kCountedThreads + tid;
+        if ((r >> 6) >= nw) break;                         // wave-uniform: whole waves vote
+        uint32_t any = 0;
+        if (r < span) {
+#pragma unroll
+            for (int e = 0; e < STRIDE; ++e) { m[u][e] = M[(size_t)(h0 + r) * STRIDE + e]; any |= __float_as_uint(m[u][e]) << 1; }   // +-0 -> 0
+        }
+        const unsigned long long votes = __ballot(any != 0u);
+        if (lane == 0) mask[r >> 6] = votes;
+    }
+    // live models in front of the chunk, and of the whole item
+    const int G = H / GROUP, g0 = h0 / GROUP;
+    int before = 0, all = 0;
+    for (int g = tid; g < G; g += kCountedThreads) {
+        const int n = counts[(size_t)b * G + g];
+        all += n;
+        before += g < g0 ? n : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+    if (lane == 0) { red[0][wave] = before; red[1][wave] = all; }
+    __syncthreads();
+    before = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    all = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { pref[w] = run; run += __popcll(mask[w]); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int r = u * kCountedThreads + tid;
+        if ((r >> 6) >= nw) break;
+        const unsigned long long w = mask[r >> 6];
+        if ((w >> lane) & 1ull) {
+            const int pos = before + pref[r >> 6] + __popcll(w & ((1ull << lane) - 1ull));
+            if (pos < H) {                                 // counts that overstate cannot push a write out of the item
+#pragma unroll
+                for (int e = 0; e < STRIDE; ++e) O[(size_t)pos * STRIDE + e] = m[u][e];
+                S[pos] = h0 + r;
+            }
+        }
+    }
+    // the zero tail, dealt over the item's blocks
+    all = min(max(all, 0), H);
+    for (int pos = all + c * kCountedThreads + tid; pos < H; pos += gridDim.x * kCountedThreads) {
+#pragma unroll
+        for (int e = 0; e < STRIDE; ++e) O[(size_t)pos * STRIDE + e] = 0.0f;
+        S[pos] = -1;
+    }
+    if (c == 0 && tid == 0) n_live[b] = all;
 }
 
 // out[b] = table[b][sel[b]] (-1 when sel[b] is outside [0, H)): compact position of a winner -> its slot
@@ -393,11 +502,12 @@ extern "C" int ph_compact_matches(const int32_t* idx, const int32_t* keep, const
                                   float* y1, float* x2, float* y2, int32_t* match_q, int32_t* match_t, int32_t* n_match,
                                   void* stream) {
     if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0) return PH_OK;
     if (!n_match) return PH_ERR_INVALID_ARG;
     if (nq > 0 && (!idx || !keep || !kp_q || !x1 || !y1 || !x2 || !y2 || (nt > 0 && !kp_t))) return PH_ERR_INVALID_ARG;
     if (!ph_aligned(kp_q, 8) || !ph_aligned(kp_t, 8)) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(compact_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, idx, keep, (const float2*)kp_q,
+    hipLaunchKernelGGL(compact_kernel, dim3(nq > 0 ? ph_ceil_div(nq, 1024) : 1, B), dim3(256), 0, (hipStream_t)stream, idx, keep, (const float2*)kp_q,
                        (const float2*)kp_t, view_q, view_t, nq, nt, x1, y1, x2, y2, match_q, match_t, n_match);
     return ph_launch_status();
 }
@@ -423,6 +533,25 @@ extern "C" int ph_compact_models(const float* models, int B, int H, int stride, 
         hipLaunchKernelGGL(compact_models_kernel<12>, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
     else
         hipLaunchKernelGGL(compact_models_kernel<0>, dim3(B), dim3(1024), 0, (hipStream_t)stream, models, H, stride, out, slot, n_live);
+    return ph_launch_status();
+}
+
+extern "C" int ph_compact_models_counted(const float* models, const int32_t* counts, int group, int B, int H, int stride,
+                                         float* out, int32_t* slot, int32_t* n_live, void* stream) {
+    if (B < 0 || H < 0 || stride < 1 || group < 1) return PH_ERR_INVALID_ARG;
+    if (H % group != 0) return PH_ERR_INVALID_ARG;
+    if (B > 65535) return PH_ERR_UNSUPPORTED;
+    if (B == 0) return PH_OK;
+    if (!n_live || (H > 0 && (!models || !out || !slot || !counts)) || models == out) return PH_ERR_INVALID_ARG;
+    const dim3 grid(ph_ceil_div(H > 0 ? H : 1, 1280), B);
+    if (stride == 9 && group == 10)
+        hipLaunchKernelGGL((compact_models_counted_kernel<9, 10>), grid, dim3(kCountedThreads), 0, (hipStream_t)stream, models,
+                           counts, H, out, slot, n_live);
+    else if (stride == 12 && group == 4)
+        hipLaunchKernelGGL((compact_models_counted_kernel<12, 4>), grid, dim3(kCountedThreads), 0, (hipStream_t)stream, models,
+                           counts, H, out, slot, n_live);
+    else                                                   // other shapes: the counts are not needed
+        return ph_compact_models(models, B, H, stride, out, slot, n_live, stream);
     return ph_launch_status();
 }
 

@@ -79,14 +79,13 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     generated = E_hyp is None
     if E_hyp is None:
         samples = ransac.sample_minimal(seed, m["n_match"], pts[0].shape[1], n_samples, item_key=item_key)
+        E_hyp, n_sol = ransac.solve_essential_5pt(*pts, samples, want_counts=True, noalloc=noalloc)
         if want_counts:
-            E_hyp, extra["n_solutions"] = ransac.solve_essential_5pt(*pts, samples, want_counts=True, noalloc=noalloc)
-        else:
-            E_hyp = ransac.solve_essential_5pt(*pts, samples, noalloc=noalloc)
+            extra["n_solutions"] = n_sol
     if generated:
         # about half of the solver's slots are empty: score the live models packed together (a wave of eight empty
         # slots leaves at once), then map the winner's compact position back to its slot — same winner, ties included
-        Ec, slot_map, _ = ransac.compact_models(E_hyp)
+        Ec, slot_map, _ = ransac.compact_models(E_hyp, counts=n_sol)      # the solver's counts place the pieces: many blocks per pair
         cnt = ransac.score_essential(Ec, *pts, thr_sq, m["n_match"], bailout=True)   # only the winner is read
         bi_c, bc = ransac.select_best(cnt)
         bi = ransac.lookup_index(slot_map, bi_c)
@@ -173,11 +172,11 @@ def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096,
     thr_sq = float(thr_px) ** 2
     samples = ransac.sample_minimal(seed, n_valid, N, n_samples, m=3) if n_valid is not None else \
         ransac.sample_minimal(seed, torch.full((B,), N, dtype=torch.int32, device=X.device), N, n_samples, m=3)
-    if want_counts:             # n_solutions [B, n_samples]: real models per minimal sample (a slot holds a model only for a solution)
-        P, n_sol = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4, want_counts=True)
-    else:
-        P, n_sol = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4), None
-    Pc, slot_map, _ = ransac.compact_models(P)                                         # live models packed (see relative_pose_front)
+    # n_solutions [B, n_samples]: real models per minimal sample (a slot holds a model only for a solution)
+    P, n_sol = ransac.solve_p3p(X, Y, Z, xn, yn, samples, K4=K4, want_counts=True)
+    Pc, slot_map, _ = ransac.compact_models(P, counts=n_sol)                           # live models packed (see relative_pose_front)
+    if not want_counts:
+        n_sol = None
     cnt = ransac.score_pnp(Pc, X, Y, Z, u, v, thr_sq, n_valid, bailout=True)          # only the winner is read; compact order
     bi_c, bc = ransac.select_best(cnt)
     bi = ransac.lookup_index(slot_map, bi_c)

@@ -105,9 +105,12 @@ def gather_models(models, sel):
     return out
 
 
-def compact_models(models):
+def compact_models(models, counts=None):
     """Live (non-zero) models of every item first, in slot order: returns (compact ``[B, H, stride]`` with a zero tail,
-    slot map int32 ``[B, H]`` (-1 in the tail), n_live int32 ``[B]``)."""
+    slot map int32 ``[B, H]`` (-1 in the tail), n_live int32 ``[B]``).
+
+    counts: int32 ``[B, H // group]`` — the solvers' ``n_solutions`` (live models per minimal sample's group of slots); with
+    them an item is packed by many blocks instead of one (``ph_compact_models_counted``).  They must be the true counts."""
     lib = L.load()
     models = L.dev(models, torch.float32, "models")
     if models.dim() != 3:
@@ -116,6 +119,13 @@ def compact_models(models):
     out = torch.empty_like(models)
     slot = torch.empty((B, H), dtype=torch.int32, device=models.device)
     n_live = torch.empty((B,), dtype=torch.int32, device=models.device)
+    if counts is not None:
+        counts = L.dev(counts, torch.int32, "counts")
+        if counts.dim() != 2 or counts.shape[0] != B or counts.shape[1] < 1 or H % counts.shape[1] != 0:
+            raise ValueError("counts must be [B, H // group]")
+        L.check(lib.ph_compact_models_counted(L.ptr(models), L.ptr(counts), H // counts.shape[1], B, H, stride, L.ptr(out),
+                                              L.ptr(slot), L.ptr(n_live), L.stream_ptr()), "ph_compact_models_counted")
+        return out, slot, n_live
     L.check(lib.ph_compact_models(L.ptr(models), B, H, stride, L.ptr(out), L.ptr(slot), L.ptr(n_live), L.stream_ptr()),
             "ph_compact_models")
     return out, slot, n_live
