@@ -748,6 +748,7 @@ __device__ __forceinline__ float exact_score(const float4* __restrict__ q, const
 constexpr int kRL = 4;
 constexpr int kRRUnroll = 4;           // chain unroll of the re-rank pass (8 spills the row loads of a pass)
 constexpr int kRQ = 64 / kRL;          // queries per wave
+constexpr int kSegGroup = 4;           // segments of a query whose list heads are loaded together (calls with split train rows)
 constexpr int kRQueue = 128;           // queue length that triggers a flush (a typical wave queues about 20 rows in all)
 struct RerankLds {
     int qj[kRQueue + 64];              // wave queue of candidates: train row ...
@@ -836,18 +837,29 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
                 bump(__int_as_float(e2.y), e2.x + 4 * (slot & 1));
             }
         }
-        for (int slot = 2; slot < slots; ++slot) {
-            const int c = cnt[o * slots + slot];
-            overflow |= c > kCapH;
-            int2 e[kE];
+        // further segments (train rows split over blocks: few pairs per call): four segments' counts and first cache lines in
+        // flight together — one at a time, a single pair's 32 segments were 30 dependent round trips (21 of the call's 30 us)
+        for (int s0 = 2; s0 < slots; s0 += kSegGroup) {
+            int c[kSegGroup];
+            int2 e[kSegGroup][kE];
 #pragma unroll
-            for (int k = 0; k < kE; ++k) e[k] = list[(o * slots + slot) * kCapH + sl + kRL * k];   // issued with the count
+            for (int g = 0; g < kSegGroup; ++g) {
+                const int slot = min(s0 + g, slots - 1);   // slots is even and kSegGroup = 4: a group may end two short
+                c[g] = s0 + g < slots ? cnt[o * slots + slot] : 0;
 #pragma unroll
-            for (int k = 0; k < kE; ++k)
-                if (sl + kRL * k < c) bump(__int_as_float(e[k].y), e[k].x + 4 * (slot & 1));
-            for (int k = sl + 16; k < c && k < kCapH; k += kRL) {
-                const int2 e2 = list[(o * slots + slot) * kCapH + k];
-                bump(__int_as_float(e2.y), e2.x + 4 * (slot & 1));
+                for (int k = 0; k < kE; ++k) e[g][k] = list[(o * slots + slot) * kCapH + sl + kRL * k];
+            }
+#pragma unroll
+            for (int g = 0; g < kSegGroup; ++g) {
+                const int slot = s0 + g;
+                overflow |= c[g] > kCapH;
+#pragma unroll
+                for (int k = 0; k < kE; ++k)
+                    if (sl + kRL * k < c[g]) bump(__int_as_float(e[g][k].y), e[g][k].x + 4 * (slot & 1));
+                for (int k = sl + 16; k < c[g] && k < kCapH; k += kRL) {
+                    const int2 e2 = list[(o * slots + slot) * kCapH + k];
+                    bump(__int_as_float(e2.y), e2.x + 4 * (slot & 1));
+                }
             }
         }
     }
@@ -984,8 +996,27 @@ __global__ __launch_bounds__(256) void l2_rerank_kernel(
                 for (int pass = kE; pass < kCapH / kRL; ++pass) from_memory(slot, pass);
         }
     }
-    for (int slot = 2; slot < max_slots; ++slot)
-        for (int pass = 0; pass < kCapH / kRL; ++pass) from_memory(slot, pass);
+    for (int s0 = 2; s0 < max_slots; s0 += kSegGroup) {    // as in (1): a group's first cache lines together, the same queue order
+        int c[kSegGroup];
+        int2 e[kSegGroup][kE];
+#pragma unroll
+        for (int g = 0; g < kSegGroup; ++g) {
+            const int slot = min(s0 + g, slots - 1);
+            c[g] = (use && s0 + g < slots) ? min(cnt[o * slots + slot], kCapH) : 0;
+#pragma unroll
+            for (int k = 0; k < kE; ++k) e[g][k] = use ? list[(o * slots + slot) * kCapH + sl + kRL * k] : make_int2(0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < kSegGroup; ++g) {
+            const int slot = s0 + g;
+            if (slot >= max_slots) break;                  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < kE; ++k)
+                enqueue((sl + kRL * k < c[g] && __int_as_float(e[g][k].y) >= bound) ? e[g][k].x + 4 * (slot & 1) : -1);
+            if (__builtin_amdgcn_ballot_w64(c[g] > 16) != 0ull)
+                for (int pass = kE; pass < kCapH / kRL; ++pass) from_memory(slot, pass);
+        }
+    }
     wave_sync();
     flush(n);
 

@@ -306,7 +306,7 @@ def inlier_mask_essential(E, sel, x1, y1, x2, y2, thr_sq, n_valid=None):
     E = _models(E, B, 9, "E")
     sel = L.opt_i32(sel, B, "sel")
     n_valid = L.opt_i32(n_valid, B, "n_valid")
-    mask = torch.zeros((B, (N + 63) // 64), dtype=torch.int64, device=E.device)
+    mask = torch.empty((B, (N + 63) // 64), dtype=torch.int64, device=E.device)      # the kernel writes every word
     L.check(lib.ph_inlier_mask_essential(L.ptr(E), L.ptr(sel), E.shape[1], L.ptr(x1), L.ptr(y1), L.ptr(x2), L.ptr(y2),
                                          L.ptr(n_valid), B, N, float(thr_sq), L.ptr(mask), L.stream_ptr()),
             "ph_inlier_mask_essential")
@@ -320,7 +320,7 @@ def inlier_mask_pnp(P, sel, X, Y, Z, u, v, thr_sq, n_valid=None):
     P = _models(P, B, 12, "P")
     sel = L.opt_i32(sel, B, "sel")
     n_valid = L.opt_i32(n_valid, B, "n_valid")
-    mask = torch.zeros((B, (N + 63) // 64), dtype=torch.int64, device=P.device)
+    mask = torch.empty((B, (N + 63) // 64), dtype=torch.int64, device=P.device)      # the kernel writes every word
     L.check(lib.ph_inlier_mask_pnp(L.ptr(P), L.ptr(sel), P.shape[1], L.ptr(X), L.ptr(Y), L.ptr(Z), L.ptr(u), L.ptr(v),
                                    L.ptr(n_valid), B, N, float(thr_sq), L.ptr(mask), L.stream_ptr()),
             "ph_inlier_mask_pnp")
