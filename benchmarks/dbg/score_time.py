@@ -37,3 +37,13 @@ frac = torch.clamp((N - best) / (N - cnt).clamp(min=1), max=1.0)     # points se
 print("ideal bail-out work fraction", float((frac * live).sum() / live.sum()))
 tc, _ = timeit(lambda: ransac.compact_models(E_slots))
 print(f"compact_models (incl. output allocation) {tc:.1f} us")
+# what a smaller seed would cost: the bound a seed of the first k packed models gives, and the work of the main launch under it
+# (a model is dropped at the first 512-point chunk boundary x with cnt(x) + (N - x) < bound; uniform inlier density)
+for k in (64, 128, 256, 576):
+    bound = cnt[:, :k].max(1, keepdim=True).values
+    x = ((N - bound) / (1.0 - p).clamp(min=1e-6)).clamp(min=0)               # cnt*x/N + N - x < bound  <=>  x > (N - bound) / (1 - p)
+    x = (torch.ceil(x / 512.0) * 512.0).clamp(max=1e9)
+    fr = torch.minimum(x / N, torch.ones_like(x))
+    rest = live.clone(); rest[:, :k] = False
+    main = float((fr * rest).sum() / live.sum()); seed = float(live[:, :k].sum() / live.sum())
+    print(f"seed {k}: bound / best {float((bound / best).mean()):.3f}, seed work {seed:.3f}, main work {main:.3f}, total {seed + main:.3f} of exhaustive")
