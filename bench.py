@@ -495,6 +495,26 @@ def main():
         "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
         "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0)"}
 
+    if rank == 0 and args.precision == 1:
+        # Context for `frac`, not a target: what the vendor's GEMM reaches on THIS box at a far easier shape (hipBLASLt through
+        # torch.matmul, fp16, 8192^3, operands resident, the product written once) — the chip's fp16 matrix rate under its
+        # power limit, against the nominal peak the fraction is taken over.
+        ga = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
+        gb = torch.randn(8192, 8192, device=dev, dtype=torch.float16)
+        for _ in range(3):
+            ga @ gb
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ga @ gb
+        e1.record()
+        torch.cuda.synchronize()
+        gemm_tf = 2.0 * 8192 ** 3 / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e12
+        roofline["vendor_gemm_same_box"] = {"what": "torch.matmul (hipBLASLt) fp16 8192 x 8192 x 8192, mean of 10", "achieved": gemm_tf,
+                                            "frac_of_peak": gemm_tf / peak, "filter_over_vendor_gemm": achieved / gemm_tf}
+        del ga, gb
+
     if args.check and rank == 0:
         from pose_estimation_amd import geometry
         tab = out["table"].cpu().numpy()
