@@ -264,17 +264,25 @@ def test_l2_batched_ragged(device, precision):
     assert np.isinf(d2[0, :400]).all()
 
 
-def test_compact_matches(device):
-    rng = np.random.default_rng(9)
-    B, nq, nt = 3, 1000, 900
+@pytest.mark.parametrize("nq,nt", [(1000, 900), (1, 5), (1024, 1024), (1025, 300), (3000, 64), (8192, 8192), (5000, 7)])
+def test_compact_matches(device, nq, nt):
+    """Stable compaction against the oracle: sizes below, at and across the 1024-query pieces a pair is cut into (a block per
+    piece counts the kept matches in front of it), indices outside [0, nt) and PH_NO_INDEX dropped, a pair without a kept
+    match, a pair that keeps everything."""
+    rng = np.random.default_rng(9 + nq)
+    B = 4
     idx = rng.integers(0, nt, (B, nq)).astype(np.int32)
     keep = (rng.random((B, nq)) < 0.4).astype(np.int32)
     keep[2] = 0
+    keep[3] = 1
+    bad = rng.random((B, nq)) < 0.05
+    idx[bad] = np.where(rng.random(int(bad.sum())) < 0.5, -1, nt + 3)      # never a match, whatever keep says
     kq = rng.standard_normal((B, nq, 2)).astype(np.float32)
     kt = rng.standard_normal((B, nt, 2)).astype(np.float32)
     out = matching.compact_matches(_t(idx, device), _t(keep, device), _t(kq, device), _t(kt, device))
     for b in range(B):
-        ref = orc.compact_matches(idx[b], keep[b], kq[b], kt[b])
+        valid = (idx[b] >= 0) & (idx[b] < nt)                 # the contract drops such rows; the oracle takes them as not kept
+        ref = orc.compact_matches(np.where(valid, idx[b], 0), keep[b] * valid, kq[b], kt[b])
         n = ref["n_match"]
         assert int(out["n_match"][b]) == n
         for k in ("x1", "y1", "x2", "y2", "match_q", "match_t"):
