@@ -241,6 +241,11 @@ int ph_score_pnp_bailout(const float* P, const float* X, const float* Y, const f
 /* argmax over hypotheses, ties -> lowest hypothesis index.  best_idx/best_count are [B]. */
 int ph_select_best(const int32_t* count, int B, int H, int32_t* best_idx, int32_t* best_count,
                    void* stream);
+/* ph_select_best over the counts of a COMPACT block (ph_compact_models*), reporting the winner's SLOT: best_idx[b] =
+ * table[b][arg-max] (table = the compaction's slot map, [B][H]; -1 for an item without a live model), best_count as
+ * ph_select_best.  One launch for ph_select_best + ph_lookup_index.  No reference counterpart (glue). */
+int ph_select_best_mapped(const int32_t* count, const int32_t* table, int B, int H, int32_t* best_idx,
+                          int32_t* best_count, void* stream);
 
 /* Inlier mask of ONE model per item: model[b] = models + (sel ? sel[b] : 0)*stride floats
  * inside item b's [H][stride] block (stride 9 / 12).  mask is [B][ceil(N/64)] 64-bit words,

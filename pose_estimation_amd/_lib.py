@@ -64,6 +64,7 @@ SIGNATURES = {
     "ph_score_essential_bailout": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "ph_score_pnp_bailout": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p]),
     "ph_select_best": (_i, [_p, _i, _i, _p, _p, _p]),
+    "ph_select_best_mapped": (_i, [_p, _p, _i, _i, _p, _p, _p]),
     "ph_inlier_mask_essential": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p]),
     "ph_inlier_mask_pnp": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p]),
     "ph_triangulate": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p]),

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void mask_kernel(const float* __restrict__ mod
 // loads in flight per thread: the headline's 9 200 counts are ONE round trip (256 threads x 8 loads were five: 12 -> 6 us).
 constexpr int kSelThreads = 1024, kSelLoads = 10;
 __global__ __launch_bounds__(kSelThreads) void select_best_kernel(const int32_t* __restrict__ count, int H,
-                                                                 int32_t* __restrict__ best_idx, int32_t* __restrict__ best_count) {
+                                                                 int32_t* __restrict__ best_idx, int32_t* __restrict__ best_count,
+                                                                 const int32_t* __restrict__ table) {
     __shared__ unsigned long long red[kSelThreads / 64];
     const int b = blockIdx.x;
     unsigned long long best = 0;
@@ -229,7 +230,8 @@ __global__ __launch_bounds__(kSelThreads) void select_best_kernel(const int32_t*
     if (threadIdx.x == 0) {
         for (int k = 1; k < kSelThreads / 64; ++k) best = red[k] > best ? red[k] : best;
         if (H > 0) {
-            best_idx[b] = (int32_t)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+            const int32_t h = (int32_t)(0xffffffffu - (uint32_t)(best & 0xffffffffu));
+            best_idx[b] = table ? table[(size_t)b * H + h] : h;       // table: the slot a compact position came from
             best_count[b] = (int32_t)(best >> 32);
         } else {
             best_idx[b] = PH_NO_INDEX;
@@ -269,8 +271,8 @@ int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int
         if (N == 0) return PH_OK;
     }
     const dim3 grid(ph_ceil_div(H, 4 * kHPW), p.psplits, B);
-    if (best_lb) ph_zero_words(best_lb, (size_t)B * PH_BAILOUT_SLOTS, st);
     if (best_lb && p.psplits == 1) {
+        ph_zero_words(best_lb, (size_t)B * PH_BAILOUT_SLOTS, st);
         // Seed launch: the first sixteenth of the hypotheses is scored first (with bail-out among themselves) and leaves
         // its best count in every counter, so the main launch knows a real final count from its first chunk on — all
         // waves of one launch start together, and running counts alone let a hopeless hypothesis go only past half
@@ -334,7 +336,16 @@ extern "C" int ph_select_best(const int32_t* count, int B, int H, int32_t* best_
     if (B < 0 || H < 0) return PH_ERR_INVALID_ARG;
     if (B == 0) return PH_OK;
     if (!best_idx || !best_count || (H > 0 && !count)) return PH_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(kSelThreads), 0, (hipStream_t)stream, count, H, best_idx, best_count);
+    hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(kSelThreads), 0, (hipStream_t)stream, count, H, best_idx, best_count, nullptr);
+    return ph_launch_status();
+}
+
+extern "C" int ph_select_best_mapped(const int32_t* count, const int32_t* table, int B, int H, int32_t* best_idx,
+                                     int32_t* best_count, void* stream) {
+    if (B < 0 || H < 0) return PH_ERR_INVALID_ARG;
+    if (B == 0) return PH_OK;
+    if (!best_idx || !best_count || (H > 0 && (!count || !table))) return PH_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(select_best_kernel, dim3(B), dim3(kSelThreads), 0, (hipStream_t)stream, count, H, best_idx, best_count, table);
     return ph_launch_status();
 }
 

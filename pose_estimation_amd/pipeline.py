@@ -87,8 +87,7 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
         # slots leaves at once), then map the winner's compact position back to its slot — same winner, ties included
         Ec, slot_map, _ = ransac.compact_models(E_hyp, counts=n_sol)      # the solver's counts place the pieces: many blocks per pair
         cnt = ransac.score_essential(Ec, *pts, thr_sq, m["n_match"], bailout=True)   # only the winner is read
-        bi_c, bc = ransac.select_best(cnt)
-        bi = ransac.lookup_index(slot_map, bi_c)
+        bi, bc = ransac.select_best(cnt, slot_map)                        # the winner's slot: arg-max + slot lookup in one launch
     else:
         cnt = ransac.score_essential(E_hyp, *pts, thr_sq, m["n_match"], bailout=True)    # only the winner is read
         bi, bc = ransac.select_best(cnt)
@@ -178,8 +177,7 @@ def absolute_pose_batch(X, Y, Z, u, v, K4, thr_px, n_valid=None, n_samples=4096,
     if not want_counts:
         n_sol = None
     cnt = ransac.score_pnp(Pc, X, Y, Z, u, v, thr_sq, n_valid, bailout=True)          # only the winner is read; compact order
-    bi_c, bc = ransac.select_best(cnt)
-    bi = ransac.lookup_index(slot_map, bi_c)
+    bi, bc = ransac.select_best(cnt, slot_map)
     mask = ransac.inlier_mask_pnp(P, bi, X, Y, Z, u, v, thr_sq, n_valid)
     pose0 = ransac.pose_from_projection(P, bi, K4)
     out = dict(pose0=pose0, best_count=bc, best_idx=bi, mask=mask, P_hyp=P, count=cnt, P_compact=Pc, slot_map=slot_map)

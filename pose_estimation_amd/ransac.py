@@ -287,13 +287,23 @@ def score_pnp(P, X, Y, Z, u, v, thr_sq, n_valid=None, bailout=False):
     return count
 
 
-def select_best(count):
-    """argmax over hypotheses, ties to the lowest index.  Returns (best_idx, best_count) int32 ``[B]``."""
+def select_best(count, slot_map=None):
+    """argmax over hypotheses, ties to the lowest index.  Returns (best_idx, best_count) int32 ``[B]``.
+
+    slot_map: the slot map of ``compact_models`` when `count` are the counts of its compact block — best_idx is then the
+    winner's SLOT (``ph_select_best_mapped``: arg-max and ``lookup_index`` in one launch; -1 for an item without a live model)."""
     lib = L.load()
     count = L.dev(count, torch.int32, "count")
     B, H = count.shape
     bi = torch.empty((B,), dtype=torch.int32, device=count.device)
     bc = torch.empty_like(bi)
+    if slot_map is not None:
+        slot_map = L.dev(slot_map, torch.int32, "slot_map")
+        if slot_map.shape != (B, H):
+            raise ValueError("slot_map must be [B, H] like count")
+        L.check(lib.ph_select_best_mapped(L.ptr(count), L.ptr(slot_map), B, H, L.ptr(bi), L.ptr(bc), L.stream_ptr()),
+                "ph_select_best_mapped")
+        return bi, bc
     L.check(lib.ph_select_best(L.ptr(count), B, H, L.ptr(bi), L.ptr(bc), L.stream_ptr()), "ph_select_best")
     return bi, bc
 

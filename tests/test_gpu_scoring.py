@@ -134,6 +134,12 @@ def test_compact_models_and_lookup(device):
         sel = torch.tensor([0, 5, H], dtype=torch.int32, device=device)
         got = ransac.lookup_index(torch.from_numpy(smap).to(device), sel).cpu().numpy()
         assert got[0] == smap[0, 0] and got[1] == -1 and got[2] == -1
+        # arg-max and lookup in one launch (ph_select_best_mapped) = the two calls
+        cnt = torch.from_numpy(rng.integers(0, 50, (B, H)).astype(np.int32)).to(device)
+        bi_c, bc = ransac.select_best(cnt)
+        want = ransac.lookup_index(torch.from_numpy(smap).to(device), bi_c)
+        bi_m, bc_m = ransac.select_best(cnt, torch.from_numpy(smap).to(device))
+        assert torch.equal(bi_m, want) and torch.equal(bc_m, bc)
 
 
 @pytest.mark.parametrize("stride,group,S", [(9, 10, 920), (9, 10, 1), (9, 10, 129), (12, 4, 4096), (12, 4, 321), (9, 5, 100)])
