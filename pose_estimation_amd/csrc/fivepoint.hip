@@ -3,12 +3,12 @@
 // no reference code (main.py only calls cv2.solvePnP); the algebra is the published one
 // (D. Nistér, "An efficient solution to the five-point relative pose problem", PAMI 2004).
 //
-// One thread per minimal sample, float64 in private memory: null space of the 5x9 epipolar system
-// (Gauss-Jordan, full pivoting, re-orthonormalised) -> the 10 cubic constraints det(E) = 0 and
-// 2EE'E - tr(EE')E = 0 as a 10x20 coefficient matrix -> Gauss-Jordan -> 3x3 polynomial matrix in z
-// -> degree-10 determinant -> all roots by Aberth-Ehrlich iteration -> for every real root the E it
-// defines, unit Frobenius norm, stored as f32 in one of the sample's 10 hypothesis slots (unused
-// slots are all-zero matrices, which score zero inliers).
+// Per minimal sample, float64 (ten lanes per sample in both stages, see below): null space of the 5x9 epipolar system
+// (Householder QR) -> the 10 cubic constraints det(E) = 0 and 2EE'E - tr(EE')E = 0 as a 10x20 coefficient matrix
+// -> Gauss-Jordan -> 3x3 polynomial matrix in z -> degree-10 determinant -> all roots by Aberth-Ehrlich iteration
+// (polynomial and derivative in f64, the repulsion term between the iterates in f32) -> Newton polish on the real axis
+// -> for every real root the E it defines, unit Frobenius norm, stored as f32 in one of the sample's 10 hypothesis
+// slots (unused slots are all-zero matrices, which score zero inliers).
 #include <math.h>
 
 #include <mutex>
@@ -356,8 +356,8 @@ __device__ __forceinline__ ph5::cplx aberth_start_fast(const double (&c)[11], in
 // Stage 2: one lane per (sample, root): 6 samples x 10 roots per wave (lanes 60-63 idle).  The ten lanes
 // of a sample run the Aberth-Ehrlich iteration together (simultaneous update, roots exchanged by
 // shuffles), then every lane turns its own root into an essential matrix and writes slot k.
-// Three waves per SIMD (168 VGPR, 7 spilled, against 192): the 2 187 one-wave blocks of 32 pairs x 410 samples then run as
-// ONE round (256 CUs x 12 waves) instead of a full round and a tail, and a wave fits beside two waves of the L2 filter.
+// 99 VGPR since the repulsion term moved to f32 (168 before): four waves per SIMD.  The occupancy hint stays (3, 8): with
+// (4, 4) the compiler drops the kernel's 96 bytes of scratch and the kernel takes 85 instead of 77 us (same box).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 8))) void fivepoint_roots_kernel(const ph5::Poly5* __restrict__ polys, long n_samples,
                                                             float* __restrict__ E_out, int32_t* __restrict__ n_sol) {
     // lanes: three groups of ten in either half of the wave, as in the polynomial stage (no group straddles lane 32)
