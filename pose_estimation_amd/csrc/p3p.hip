@@ -27,7 +27,7 @@ __global__ __launch_bounds__(128) void p3p_kernel(const float* __restrict__ X, c
         const size_t o = (size_t)b * N + (ok ? i : 0);
         Xw[r][0] = X[o]; Xw[r][1] = Y[o]; Xw[r][2] = Z[o];
         const double x = u[o], y = v[o];
-        const double inv = 1.0 / sqrt(x * x + y * y + 1.0);
+        const double inv = ph5::fast_rsqrt(x * x + y * y + 1.0);
         f[r][0] = x * inv; f[r][1] = y * inv; f[r][2] = inv;
     }
     double Rt[4][12];

@@ -23,6 +23,8 @@ namespace p3p {
 using ph5::cinv;
 using ph5::cmul;
 using ph5::cplx;
+using ph5::fast_rcp;      // on the device: v_rcp_f64 / v_rsq_f64 + two Newton steps (~2^-50) instead of IEEE division / sqrt
+using ph5::fast_rsqrt;    // (~25 dependent instructions each; this solver had about sixty of them per sample); host: exact
 
 PH_HD_CONST int kMaxIter = 40;
 PH_HD_CONST double kTol = 1e-14;
@@ -38,14 +40,16 @@ PH_HD inline void cross3(const double* a, const double* b, double* c) {
 PH_HD inline bool triangle_frame(const double* p1, const double* p2, const double* p3, double (&E)[3][3]) {
     double d12[3], d13[3];
     for (int k = 0; k < 3; ++k) { d12[k] = p2[k] - p1[k]; d13[k] = p3[k] - p1[k]; }
-    const double n1 = sqrt(dot3(d12, d12));
-    if (!(n1 > 0.0)) return false;
-    for (int k = 0; k < 3; ++k) E[0][k] = d12[k] / n1;
+    const double q1 = dot3(d12, d12);
+    if (!(q1 > 0.0)) return false;
+    const double r1 = fast_rsqrt(q1);
+    for (int k = 0; k < 3; ++k) E[0][k] = d12[k] * r1;
     double w[3];
     cross3(E[0], d13, w);
-    const double n3 = sqrt(dot3(w, w));
-    if (!(n3 > 1e-12 * sqrt(dot3(d13, d13)))) return false;
-    for (int k = 0; k < 3; ++k) E[2][k] = w[k] / n3;
+    const double q3 = dot3(w, w);
+    if (!(q3 > 1e-24 * dot3(d13, d13))) return false;      // |w| > 1e-12 |d13|
+    const double r3 = fast_rsqrt(q3);
+    for (int k = 0; k < 3; ++k) E[2][k] = w[k] * r3;
     cross3(E[2], E[0], E[1]);
     return true;
 }
@@ -86,15 +90,19 @@ PH_HD inline int solve(const double (&X)[3][3], const double (&f)[3][3], double 
     double cmax = 0.0;
     for (int k = 0; k <= 4; ++k) cmax = fmax(cmax, fabs(c[k]));
     if (!(cmax > 0.0) || !(cmax < HUGE_VAL)) return 0;
-    for (int k = 0; k <= 4; ++k) c[k] /= cmax;
+    {
+        const double rc = fast_rcp(cmax);
+        for (int k = 0; k <= 4; ++k) c[k] *= rc;
+    }
     constexpr int n = 4;                       // fixed degree keeps every array below in registers on the device
     if (!(fabs(c[4]) > 1e-30)) return 0;       // a vanishing leading coefficient (measure-zero configuration): no hypotheses
 
     // Aberth-Ehrlich on the four roots
     cplx z[4];
     {
-        double rad = pow(fabs(c[0] / c[n]) + 1e-300, 1.0 / n);
-        rad = fmin(fmax(rad, 1e-3), 1e3);
+        // fourth root of |c0 / c4|, clamped to [1e-3, 1e3]: two f32 square roots (start values need no more)
+        const float x4 = (float)fmin(fmax(fabs(c[0] * fast_rcp(c[n])), 1e-12), 1e12);
+        const double rad = (double)sqrtf(sqrtf(x4));
 #pragma unroll
         for (int k = 0; k < n; ++k) {
             const double ang = 6.283185307179586 * k / n + 0.4;
@@ -125,13 +133,13 @@ PH_HD inline int solve(const double (&X)[3][3], const double (&f)[3][3], double 
             const cplx s = cmul(nw, cinv(den));
             if (s.re == s.re && s.im == s.im) w[k] = s;
         }
-        double worst = 0.0;
+        bool settled = true;                       // every root's relative change below kTol
 #pragma unroll
         for (int k = 0; k < n; ++k) {
             z[k].re -= w[k].re; z[k].im -= w[k].im;
-            worst = fmax(worst, (fabs(w[k].re) + fabs(w[k].im)) / (fabs(z[k].re) + fabs(z[k].im) + 1e-30));
+            settled = settled && (fabs(w[k].re) + fabs(w[k].im) < kTol * (fabs(z[k].re) + fabs(z[k].im) + 1e-30));
         }
-        if (worst < kTol) break;
+        if (settled) break;
     }
 
     int ns = 0;
@@ -144,9 +152,9 @@ PH_HD inline int solve(const double (&X)[3][3], const double (&f)[3][3], double 
         const double Nv = (N[2] * v + N[1]) * v + N[0], Dv = D[1] * v + D[0];
         double u;
         if (fabs(Dv) > 1e-9 * b2) {
-            u = Nv / Dv;
+            u = Nv * fast_rcp(Dv);
         } else {   // D(v) = 0: u from  b2 (1 + u^2 - 2 u cg) = c2 Q(v),  the root that also satisfies the first equation
-            const double disc = cg * cg - 1.0 + c2 * Qv / b2;
+            const double disc = cg * cg - 1.0 + c2 * Qv * fast_rcp(b2);
             if (!(disc >= 0.0)) continue;
             const double r = sqrt(disc), u1 = cg + r, u2 = cg - r;
             const double e1 = fabs(b2 * (u1 * u1 + v * v - 2.0 * u1 * v * ca) - a2 * Qv);
@@ -155,7 +163,10 @@ PH_HD inline int solve(const double (&X)[3][3], const double (&f)[3][3], double 
         }
         if (!(u > 0.0) || !(Qv > 0.0)) continue;
         double s[3];
-        s[0] = sqrt(b2 / Qv); s[1] = u * s[0]; s[2] = v * s[0];
+        {
+            const double t = b2 * fast_rcp(Qv);            // s1 = sqrt(b2 / Q(v)); t > 0 here
+            s[0] = t * fast_rsqrt(t); s[1] = u * s[0]; s[2] = v * s[0];
+        }
         // two Gauss-Newton steps on the three law-of-cosines equations, then the residual test
         double res = 0.0;
         for (int it = 0; it < 3; ++it) {
@@ -169,8 +180,8 @@ PH_HD inline int solve(const double (&X)[3][3], const double (&f)[3][3], double 
             const double J20 = 2.0 * (s[0] - s[1] * cg), J21 = 2.0 * (s[1] - s[0] * cg);
             // J = [0 J01 J02; J10 0 J12; J20 J21 0]
             const double det = J01 * J12 * J20 + J02 * J10 * J21;
-            if (!(fabs(det) > 1e-12 * scale * sqrt(scale))) continue;
-            const double id = 1.0 / det;
+            if (!(det * det > 1e-24 * scale * scale * scale)) continue;     // |det| > 1e-12 scale^1.5
+            const double id = fast_rcp(det);
             // adjugate of J times g
             const double d0 = (-J12 * J21) * g0 + (J02 * J21) * g1 + (J01 * J12) * g2;
             const double d1 = (J12 * J20) * g0 + (-J02 * J20) * g1 + (J02 * J10) * g2;
