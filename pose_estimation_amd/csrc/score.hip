@@ -42,14 +42,18 @@ __device__ __forceinline__ bool pnp_inlier(const float (&P)[12], float X, float 
     return (w > 0.0f) && (e2 < thr_sq * (w * w));
 }
 
+// kSeedDiv: the seed launch of the bail-out scoring takes the first 1 / kSeedDiv of the hypothesis block.  Minimal-sample essential
+// matrices: few models come near the best count (17 of 4 330 within 10 %), a sixteenth of them is what it takes to hold one
+// (benchmarks/dbg/score_time.py: 64 / 128 / 256 / 576 seed models -> 0.587 / 0.546 / 0.531 / 0.541 of the exhaustive work);
+// P3P poses on 70 % inliers: a third of the models are good ones, a 64th of the block is seed enough (cfg 5: 7.28 against 7.49 ms).
 struct EssentialModel {
-    static constexpr int kParams = 9, kArrays = 4;
+    static constexpr int kParams = 9, kArrays = 4, kSeedDiv = 16;
     __device__ static __forceinline__ bool test(const float (&m)[9], const float (&p)[4], float thr_sq) {
         return sampson_inlier(m, p[0], p[1], p[2], p[3], thr_sq);
     }
 };
 struct PnpModel {
-    static constexpr int kParams = 12, kArrays = 5;
+    static constexpr int kParams = 12, kArrays = 5, kSeedDiv = 64;
     __device__ static __forceinline__ bool test(const float (&m)[12], const float (&p)[5], float thr_sq) {
         return pnp_inlier(m, p[0], p[1], p[2], p[3], p[4], thr_sq);
     }
@@ -278,7 +282,7 @@ int score_launch(const float* models, PointArrays<Model::kArrays> pts, const int
         // waves of one launch start together, and running counts alone let a hopeless hypothesis go only past half
         // of its points.
         int h_seed = 0;
-        if (H >= 1024) h_seed = ph_ceil_div(H / 16, 4 * kHPW) * (4 * kHPW);
+        if (H >= 1024) h_seed = ph_ceil_div(H / Model::kSeedDiv, 4 * kHPW) * (4 * kHPW);
         if (h_seed > 0)
             hipLaunchKernelGGL((score_kernel<Model, true>), dim3(h_seed / (4 * kHPW), 1, B), dim3(256), 0, st, models, pts,
                                n_valid, H, N, 1, p.pts_per_split, thr_sq, count, best_lb, 0, h_seed, 1);
