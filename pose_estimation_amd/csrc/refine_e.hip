@@ -19,7 +19,8 @@
 
 namespace {
 
-constexpr int kNT = 512;          // 8 waves: two per SIMD of one CU (the 5 derivative matrices stay in registers)
+constexpr int kNT = 512;          // 8 waves: two per SIMD of one CU (the 5 derivative matrices stay in registers); 1024 threads = 128
+                                  // VGPR spill 148 bytes of thread 0's 5 x 5 algebra: 84 against 56 us
 constexpr int kNW = kNT / 64;
 constexpr int kSums = 23;          // 15 (J'J upper) + 5 (J'r) + ssq + n_inside + n_valid
 
