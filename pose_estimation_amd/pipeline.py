@@ -85,7 +85,7 @@ def relative_pose_front(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
     if generated:
         # about half of the solver's slots are empty: score the live models packed together (a wave of eight empty
         # slots leaves at once), then map the winner's compact position back to its slot — same winner, ties included
-        Ec, slot_map, _ = ransac.compact_models(E_hyp, counts=n_sol)      # the solver's counts place the pieces: many blocks per pair
+        Ec, slot_map, extra["n_live"] = ransac.compact_models(E_hyp, counts=n_sol)    # the solver's counts place the pieces: many blocks per pair
         cnt = ransac.score_essential(Ec, *pts, thr_sq, m["n_match"], bailout=True)   # only the winner is read
         bi, bc = ransac.select_best(cnt, slot_map)                        # the winner's slot: arg-max + slot lookup in one launch
     else:
@@ -142,7 +142,8 @@ def relative_pose_batch(match, kp_q, kp_t, view_q, view_t, E_hyp, thr_sq, ratio=
                         n_samples=410, seed=0, decompose="device", item_key=None, want_counts=False, refine=True,
                         noalloc=False):
     """front + back for one batch of B pairs.  Returns dict(table [B,16] device f32, n_match, best_idx,
-    best_count, mask, E_hyp, front, win and, with want_points, xyz / pts).
+    best_count, mask, E_hyp, front, win and, with want_points, xyz / pts; when the hypotheses were generated here also
+    n_live int32 [B], the number of real models of every pair, and with want_counts n_solutions [B, n_samples]).
 
     With refine=True the table's R | t are the LM-refined pose; best_idx, best_count (table column 12), mask, front and
     win still describe the winning minimal-sample hypothesis the refinement started from (its RANSAC support), and xyz
