@@ -24,12 +24,15 @@ __device__ __forceinline__ void rotate_cols(float (&A)[4][4], float (&V)[4][4], 
         gamma = ph_fma(A[r][p], A[r][q], gamma);
     }
     // rotation angle that zeroes the (p,q) inner product; t = tan(theta), |t| <= 1
-    const float zeta = (beta - alpha) * __frcp_rn(2.0f * gamma);
+    // v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 themselves (1 ulp): the correctly rounded forms expand to a division by scale / fmas /
+    // fixup and a range-scaled square root — 30 of a sweep's ~300 instructions were v_div_scale alone — and a Jacobi rotation
+    // by an angle that is off in its last bit still orthogonalises: the next sweep takes what is left
+    const float zeta = (beta - alpha) * __builtin_amdgcn_rcpf(2.0f * gamma);
     const float az = fabsf(zeta);
-    float t = __frcp_rn(az + __fsqrt_rn(ph_fma(zeta, zeta, 1.0f)));
+    float t = __builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(ph_fma(zeta, zeta, 1.0f)));
     t = (zeta < 0.0f) ? -t : t;
     t = (gamma == 0.0f || !(az < INFINITY)) ? 0.0f : t;
-    const float c = __frsqrt_rn(ph_fma(t, t, 1.0f));
+    const float c = __builtin_amdgcn_rsqf(ph_fma(t, t, 1.0f));
     const float s = c * t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void triangulate_kernel(const float* __restric
         best = lt ? n2 : best;
         hx = lt ? V[0][k] : hx; hy = lt ? V[1][k] : hy; hz = lt ? V[2][k] : hz; hw = lt ? V[3][k] : hw;
     }
-    const float X = hx / hw, Y = hy / hw, Z = hz / hw;
+    const float rw = 1.0f / hw;                            // one correctly rounded reciprocal for the point itself
+    const float X = hx * rw, Y = hy * rw, Z = hz * rw;
     if (ok && XYZ) {
         float* dst = XYZ + (((size_t)b * C + c) * N + i) * 3;
         dst[0] = X; dst[1] = Y; dst[2] = Z;
