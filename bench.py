@@ -495,7 +495,8 @@ def main():
         "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
         "note": "outputs are bit-identical to the f32 MFMA matcher (--precision 0)"}
 
-    if rank == 0 and args.precision == 1:
+    if rank == 0 and args.precision == 1 and not args.no_other_configs:      # (profiled runs pass --no-other-configs: their kernel
+                                                                             # statistics then hold the step's kernels only)
         # Context for `frac`, not a target: what the vendor's GEMM reaches on THIS box at a far easier shape (hipBLASLt through
         # torch.matmul, fp16, 8192^3, operands resident, the product written once) — the chip's fp16 matrix rate under its
         # power limit, against the nominal peak the fraction is taken over.
