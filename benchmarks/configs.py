@@ -71,7 +71,7 @@ def run_allpairs(cfg, f32, dev, n_pairs=0, samples=410, chunk=64, n_streams=3, v
     if n_pairs:
         vi, vj = vi[:n_pairs], vj[:n_pairs]
     thr_sq = float(np.float32((1.5 / synthetic.FX) ** 2))
-    run = AllPairs(desc, kp, norms, thr_sq, samples, f32, refine=refine)
+    run = AllPairs(desc, kp, norms, thr_sq, samples, f32, refine=refine, resident_images=os.environ.get("POSEHOT_RESIDENT_IMAGES", "1") != "0")
 
     w = min(chunk, len(vi))                 # warm-up chunk (also the first real chunk's shapes), outside the timed region
     run.chunk(0, torch.arange(w), vi[:w], vj[:w]); run.reset_counts()

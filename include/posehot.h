@@ -69,6 +69,24 @@ int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_t,
                           int32_t* idx, int32_t* d1, int32_t* d2,
                           void* ws, size_t ws_bytes, void* stream);
 
+/* The same matcher over RESIDENT train-side images (views that are matched again and again — all-pairs runs: BASELINE.json
+ * configs[2], [3]): ph_match_hamming_top2 first expands the train view of every pair of the call into the form the matrix cores
+ * read (128 bytes per row); ph_hamming_expand_views does that ONCE for all V views of a table into `images`
+ * (ph_hamming_view_images_bytes(V, nt) bytes: 1.05 GB for 1 000 views of 8 192 rows), and ph_match_hamming_top2_images reads
+ * them by view_t[b] instead.  Same outputs, bit for bit; the workspace holds the split partials only
+ * (ph_match_hamming_images_ws_bytes, 0 for calls that do not split the train rows).  desc_t is still read (a query's best
+ * group of four rows is resolved from the bits).  No reference counterpart. */
+size_t ph_hamming_view_images_bytes(int V, int nt);
+int ph_hamming_expand_views(const uint8_t* desc_t, int V, int nt, int bytes, void* images, size_t images_bytes,
+                            void* stream);
+size_t ph_match_hamming_images_ws_bytes(int B, int nq, int nt);
+int ph_match_hamming_top2_images(const uint8_t* desc_q, const uint8_t* desc_t, const void* images,
+                                 const int32_t* view_q, const int32_t* view_t,
+                                 const int32_t* n_q, const int32_t* n_t,
+                                 int B, int nq, int nt, int bytes,
+                                 int32_t* idx, int32_t* d1, int32_t* d2,
+                                 void* ws, size_t ws_bytes, void* stream);
+
 /* Squared row norms |a_r|^2 of a [n_rows][dim] f32 table (natural-order fma chain from 0),
  * computed ONCE per view table and reused by every pair that touches the view. */
 int ph_row_sqnorm(const float* table, int64_t n_rows, int dim, float* out, void* stream);

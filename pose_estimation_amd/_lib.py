@@ -38,6 +38,10 @@ SIGNATURES = {
     "ph_status_string": (C.c_char_p, [_i]),
     "ph_match_hamming_ws_bytes": (_sz, [_i, _i, _i]),
     "ph_match_hamming_top2": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "ph_hamming_view_images_bytes": (_sz, [_i, _i]),
+    "ph_hamming_expand_views": (_i, [_p, _i, _i, _i, _p, _sz, _p]),
+    "ph_match_hamming_images_ws_bytes": (_sz, [_i, _i, _i]),
+    "ph_match_hamming_top2_images": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "ph_match_l2_ws_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ph_row_sqnorm": (_i, [_p, _i64, _i, _p, _p]),
     "ph_match_l2_top2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     const int32_t* __restrict__ view_q, const int32_t* __restrict__ n_q, const int32_t* __restrict__ n_t,
     int nq, int nt, int splits, int rows_per_split,
     int32_t* __restrict__ idx, int32_t* __restrict__ d1, int32_t* __restrict__ d2,
-    uint2* __restrict__ partial, const uint4* __restrict__ dt_raw, const int32_t* __restrict__ view_t) {
+    uint2* __restrict__ partial, const uint4* __restrict__ dt_raw, const int32_t* __restrict__ view_t, int img_by_view) {
     __shared__ uint4 smem[3 * kHImg];             // ring of three staged tiles (ONE LDS object beside the DMA target)
     static_assert(kHImgRows % 256 == 0, "staging deal");
     constexpr int kGlds = kHImgRows / 256;        // LDS-DMA instructions per wave per staged tile
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256, QT == 1 ? 4 : 3) void hamming_fp4_dma_kernel(
     const int nqv = n_q ? min(max(n_q[b], 0), nq) : nq;
     const int ntv = n_t ? min(max(n_t[b], 0), nt) : nt;
     const uint4* Q = dq + (size_t)vq * nq * 2;
-    const uint4* IMG = img + (size_t)b * tiles * kHImg;
+    // the pair's tile images: written for this call (by pair), or the caller's resident images of every view (by train view:
+    // ph_hamming_expand_views; rows at or beyond the pair's valid count are masked below whatever the image holds)
+    const uint4* IMG = img + (size_t)(img_by_view ? (view_t ? view_t[b] : b) : b) * tiles * kHImg;
     const int qw0 = (xq * 4 + wave) * (32 * QT);
 
     uint4 bq[QT][4];
@@ -366,38 +368,45 @@ extern "C" size_t ph_match_hamming_ws_bytes(int B, int nq, int nt) {
     return plan_hamming_mfma(B, nq, nt).total;
 }
 
-extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_t,
-                                     const int32_t* view_q, const int32_t* view_t,
-                                     const int32_t* n_q, const int32_t* n_t,
-                                     int B, int nq, int nt, int bytes,
-                                     int32_t* idx, int32_t* d1, int32_t* d2,
-                                     void* ws, size_t ws_bytes, void* stream) {
+namespace {
+// images == nullptr: the train views of the call's pairs are expanded into the workspace first (by pair); else `images` holds
+// the expanded tiles of EVERY view of desc_t (ph_hamming_expand_views) and nothing is expanded here.
+int hamming_launch(const uint8_t* desc_q, const uint8_t* desc_t, const void* images,
+                   const int32_t* view_q, const int32_t* view_t, const int32_t* n_q, const int32_t* n_t,
+                   int B, int nq, int nt, int bytes, int32_t* idx, int32_t* d1, int32_t* d2,
+                   void* ws, size_t ws_bytes, void* stream) {
     if (B < 0 || nq < 0 || nt < 0) return PH_ERR_INVALID_ARG;
     if (bytes != 32) return PH_ERR_UNSUPPORTED;
     if (nt > (int)kIdxMask || B > 65535) return PH_ERR_UNSUPPORTED;
     if (B == 0 || nq == 0) return PH_OK;
     if (!desc_q || !idx || !d1 || !d2 || (nt > 0 && !desc_t)) return PH_ERR_INVALID_ARG;
-    if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16)) return PH_ERR_INVALID_ARG;
+    if (!ph_aligned(desc_q, 16) || !ph_aligned(desc_t, 16) || !ph_aligned(images, 16)) return PH_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     const HammingMfmaPlan p = (nt > 0) ? plan_hamming_mfma(B, nq, nt) : HammingMfmaPlan{1, 1, kHSR, 0, 0, 0};
-    if (p.total > 0) {
-        if (!ws || ws_bytes < p.total || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
+    const size_t need = images ? p.off_img : p.total;          // resident images: only the split partials live in the workspace
+    if (need > 0) {
+        if (!ws || ws_bytes < need || !ph_aligned(ws, 16)) return PH_ERR_WORKSPACE;
     }
     const dim3 grid(ph_ceil_div(nq, 128 * p.qt), p.splits, B);
     const uint4* q4 = (const uint4*)desc_q;
     const uint32_t* t1 = (const uint32_t*)desc_t;
     uint2* part = (uint2*)ws;
     if (nt > 0) {
-        uint4* img = (uint4*)((char*)ws + p.off_img);
-        hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, t1, view_t, n_t, nt,
-                           p.tiles, img);
+        const uint4* img = (const uint4*)images;
+        if (!images) {
+            uint4* own = (uint4*)((char*)ws + p.off_img);
+            hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((size_t)B * p.tiles)), dim3(256), 0, st, t1, view_t, n_t, nt,
+                               p.tiles, own);
+            img = own;
+        }
+        const int by_view = images ? 1 : 0;
 #define PH_LAUNCH(QT) hipLaunchKernelGGL(hamming_fp4_dma_kernel<QT>, grid, dim3(256), 0, st, q4, img, p.tiles, view_q, n_q, n_t, \
-                                         nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part, (const uint4*)t1, view_t)
+                                         nq, nt, p.splits, p.rows_per_split, idx, d1, d2, part, (const uint4*)t1, view_t, by_view)
         if (p.qt == 2) PH_LAUNCH(2); else PH_LAUNCH(1);
 #undef PH_LAUNCH
     } else {                                   // no train rows: every query gets "no neighbour"
         hipLaunchKernelGGL(hamming_fp4_dma_kernel<1>, grid, dim3(256), 0, st, q4, (const uint4*)nullptr, 0, view_q, n_q, n_t, nq,
-                           nt, p.splits, p.rows_per_split, idx, d1, d2, part, (const uint4*)nullptr, view_t);
+                           nt, p.splits, p.rows_per_split, idx, d1, d2, part, (const uint4*)nullptr, view_t, 0);
     }
     if (p.splits > 1) {
         const size_t n = (size_t)B * nq;
@@ -405,6 +414,49 @@ extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_
                            p.splits, idx, d1, d2);
     }
     return ph_launch_status();
+}
+}  // namespace
+
+extern "C" int ph_match_hamming_top2(const uint8_t* desc_q, const uint8_t* desc_t,
+                                     const int32_t* view_q, const int32_t* view_t,
+                                     const int32_t* n_q, const int32_t* n_t,
+                                     int B, int nq, int nt, int bytes,
+                                     int32_t* idx, int32_t* d1, int32_t* d2,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    return hamming_launch(desc_q, desc_t, nullptr, view_q, view_t, n_q, n_t, B, nq, nt, bytes, idx, d1, d2, ws, ws_bytes, stream);
+}
+
+extern "C" size_t ph_hamming_view_images_bytes(int V, int nt) {
+    if (V <= 0 || nt <= 0) return 0;
+    return sizeof(uint4) * (size_t)V * ph_ceil_div(nt, kHSR) * kHImg;
+}
+
+extern "C" int ph_hamming_expand_views(const uint8_t* desc_t, int V, int nt, int bytes, void* images, size_t images_bytes,
+                                       void* stream) {
+    if (V < 0 || nt < 0) return PH_ERR_INVALID_ARG;
+    if (bytes != 32) return PH_ERR_UNSUPPORTED;
+    if (V == 0 || nt == 0) return PH_OK;
+    if (!desc_t || !images || !ph_aligned(desc_t, 16) || !ph_aligned(images, 16)) return PH_ERR_INVALID_ARG;
+    if (images_bytes < ph_hamming_view_images_bytes(V, nt)) return PH_ERR_WORKSPACE;
+    const int tiles = ph_ceil_div(nt, kHSR);
+    hipLaunchKernelGGL(hamming_expand_kernel, dim3((unsigned)((size_t)V * tiles)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)desc_t, (const int32_t*)nullptr, (const int32_t*)nullptr, nt, tiles, (uint4*)images);
+    return ph_launch_status();
+}
+
+extern "C" size_t ph_match_hamming_images_ws_bytes(int B, int nq, int nt) {
+    if (B <= 0 || nq <= 0 || nt <= 0) return 0;
+    return plan_hamming_mfma(B, nq, nt).off_img;
+}
+
+extern "C" int ph_match_hamming_top2_images(const uint8_t* desc_q, const uint8_t* desc_t, const void* images,
+                                            const int32_t* view_q, const int32_t* view_t,
+                                            const int32_t* n_q, const int32_t* n_t,
+                                            int B, int nq, int nt, int bytes,
+                                            int32_t* idx, int32_t* d1, int32_t* d2,
+                                            void* ws, size_t ws_bytes, void* stream) {
+    if (nt > 0 && !images) return PH_ERR_INVALID_ARG;
+    return hamming_launch(desc_q, desc_t, images, view_q, view_t, n_q, n_t, B, nq, nt, bytes, idx, d1, d2, ws, ws_bytes, stream);
 }
 
 extern "C" int ph_ratio_filter_hamming(const int32_t* idx, const int32_t* d1, const int32_t* d2, int64_t n,

@@ -32,8 +32,25 @@ def _chunks(B):
         yield s, min(B, s + MAX_ITEMS)
 
 
-def match_hamming(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None):
-    """Hamming top-2.  Returns (idx, d1, d2), each int32 ``[B, nq]``."""
+def hamming_view_images(desc_t):
+    """The matrix-core images of EVERY view of a ``[V, n, 32]`` uint8 table, expanded once (``ph_hamming_expand_views``; 128 bytes
+    per row, resident): hand them to ``match_hamming(..., images=...)`` when the same views are matched again and again."""
+    lib = L.load()
+    desc_t = L.dev(desc_t, torch.uint8, "desc_t")
+    if desc_t.dim() != 3 or desc_t.shape[2] != 32:
+        raise ValueError("descriptor table must be [V, n, 32] uint8")
+    V, nt = desc_t.shape[0], desc_t.shape[1]
+    nbytes = lib.ph_hamming_view_images_bytes(V, nt)
+    images = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=desc_t.device)
+    L.check(lib.ph_hamming_expand_views(L.ptr(desc_t), V, nt, 32, L.ptr(images), nbytes, L.stream_ptr()), "ph_hamming_expand_views")
+    return images
+
+
+def match_hamming(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None, images=None):
+    """Hamming top-2.  Returns (idx, d1, d2), each int32 ``[B, nq]``.
+
+    images: ``hamming_view_images(desc_t)`` — the train views' images are then read where they lie instead of being expanded
+    for the call's pairs (same outputs, bit for bit)."""
     lib = L.load()
     desc_q = L.dev(desc_q, torch.uint8, "desc_q")
     desc_t = L.dev(desc_t, torch.uint8, "desc_t")
@@ -53,9 +70,19 @@ def match_hamming(desc_q, desc_t, view_q=None, view_t=None, n_q=None, n_t=None):
     d2 = torch.empty_like(idx)
     for s, e in _chunks(B):
         nb = e - s
+        sl = lambda t: None if t is None else t[s:e]
+        if images is not None:
+            if view_t is None and B > 1 and (s, e) != (0, B):
+                raise ValueError("resident images with an implicit view list need the whole pair list in one call")
+            wsb = lib.ph_match_hamming_images_ws_bytes(nb, nq, nt)
+            ws = L.workspace(wsb, dev)
+            L.check(lib.ph_match_hamming_top2_images(L.ptr(desc_q if view_q is not None else desc_q[s:e]), L.ptr(desc_t),
+                                                     L.ptr(images), L.ptr(sl(view_q)), L.ptr(sl(view_t)), L.ptr(sl(n_q)),
+                                                     L.ptr(sl(n_t)), nb, nq, nt, nbytes, L.ptr(idx[s:e]), L.ptr(d1[s:e]),
+                                                     L.ptr(d2[s:e]), L.ptr(ws), wsb, L.stream_ptr()), "ph_match_hamming_top2_images")
+            continue
         wsb = lib.ph_match_hamming_ws_bytes(nb, nq, nt)
         ws = L.workspace(wsb, dev)
-        sl = lambda t: None if t is None else t[s:e]
         # with view lists the tables are shared; without, pair b uses view b of each table
         q = desc_q if view_q is not None else desc_q[s:e]
         t = desc_t if view_t is not None else desc_t[s:e]

@@ -373,3 +373,26 @@ def test_l2_own_norms_when_the_provisional_scales_do_not_stand(device):
         _assert_same_bits(want, matching.match_l2(tq, tt, vq, vt, nq_, nt_, precision=1))
     finally:
         matching.OWN_NORMS = saved
+
+
+@pytest.mark.parametrize("V,n,B", [(3, 300, 5), (2, 64, 2), (4, 2049, 6), (1, 1, 1), (2, 8192, 1), (5, 1000, 64)])
+def test_hamming_resident_view_images_equal_the_per_call_expansion(device, V, n, B):
+    """ph_hamming_expand_views + ph_match_hamming_top2_images (train-side images of every view expanded once, read by view) give
+    what ph_match_hamming_top2 gives, bit for bit: view lists, ragged valid counts (rows beyond a pair's n_t are in the resident
+    image and must be masked), one pair with split train rows, many pairs."""
+    rng = np.random.default_rng(50 + n + B)
+    tab = _t(rng.integers(0, 256, (V, n, 32), dtype=np.uint8), device)
+    vq = _t(rng.integers(0, V, B).astype(np.int32), device); vt = _t(rng.integers(0, V, B).astype(np.int32), device)
+    n_q = rng.integers(0, n + 1, B).astype(np.int32); n_t = rng.integers(0, n + 1, B).astype(np.int32)
+    n_q[0] = n; n_t[0] = n
+    images = matching.hamming_view_images(tab)
+    for nq_, nt_ in ((None, None), (_t(n_q, device), _t(n_t, device))):
+        ref = matching.match_hamming(tab, tab, vq, vt, nq_, nt_)
+        got = matching.match_hamming(tab, tab, vq, vt, nq_, nt_, images=images)
+        for r, g in zip(ref, got):
+            assert torch.equal(r, g)
+    if B <= V:                                            # implicit view lists: pair b = view b of either table
+        ref = matching.match_hamming(tab[:B], tab[:B])
+        got = matching.match_hamming(tab[:B], tab[:B], images=matching.hamming_view_images(tab[:B]))
+        for r, g in zip(ref, got):
+            assert torch.equal(r, g)
