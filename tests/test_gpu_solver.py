@@ -6,6 +6,8 @@ solution must satisfy the essential-matrix constraints and have a counterpart in
 solver's solution set within 1e-5 (Frobenius, up to sign), and on noise-free samples the true E
 must be among them.  No reference code exists for either: parity unpinned.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,6 +16,7 @@ from oracle import fivepoint as fp
 from pose_estimation_amd import ransac, synthetic
 
 pytestmark = pytest.mark.gpu
+_SEEDS = list(range(1 + int(os.environ.get("POSEHOT_SOLVER_SOAK", "0"))))     # seed 0 = the committed case; more for a one-off soak
 
 
 def _t(a, device):
@@ -52,12 +55,13 @@ def _scene(seed, n, noise=0.0, yaw=-10.0):
     return x1.astype(np.float32), x2.astype(np.float32), E / np.linalg.norm(E)
 
 
+@pytest.mark.parametrize("seed", _SEEDS)
 @pytest.mark.parametrize("noise,yaw", [(0.0, -10.0), (1.0 / 3108.95, -10.0), (0.0, 120.0)])
-def test_fivepoint_matches_numpy_and_constraints(device, noise, yaw):
+def test_fivepoint_matches_numpy_and_constraints(device, noise, yaw, seed):
     n, S = 500, 200
-    x1, x2, Et = _scene(3, n, noise, yaw)
+    x1, x2, Et = _scene(3 + 17 * seed, n, noise, yaw)
     nv = _t(np.array([n], np.int32), device)
-    samples = ransac.sample_minimal(7, nv, n, S)
+    samples = ransac.sample_minimal(7 + seed, nv, n, S)
     args = [_t(a[None], device) for a in (x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1])]
     E, ns = ransac.solve_essential_5pt(*args, samples, want_counts=True)
     E = E.cpu().numpy()[0].reshape(S, 10, 3, 3).astype(np.float64); ns = ns.cpu().numpy()[0]
@@ -65,15 +69,21 @@ def test_fivepoint_matches_numpy_and_constraints(device, noise, yaw):
     a = [v.astype(np.float64) for v in (x1[:, 0], x1[:, 1], x2[:, 0], x2[:, 1])]
     ref = fp.solve(*(v[si] for v in a))
     found_true, found_true_ref, matched, total, same_count = 0, 0, 0, 0, 0
+    over, over_ref, worst = 0, 0, 0.0
     for s in range(S):
         k = int(ns[s])
         sol = E[s][np.abs(E[s]).sum(axis=(1, 2)) > 0]          # slot = root index; non-real roots are zero slots
         assert len(sol) == k
         same_count += (k == len(ref[s]))
+        for e in ref[s]:
+            _, cub, det = fp.essential_residuals(e, *(v[si[s]] for v in a))
+            over_ref += not (cub < 1e-4 and det < 1e-4)
         for e in sol:
             assert abs(np.linalg.norm(e) - 1) < 1e-6
             epi, cub, det = fp.essential_residuals(e, *(v[si[s]] for v in a))
-            assert epi < 1e-5 and cub < 1e-4 and det < 1e-4          # f32 storage; near-double roots are the loosest
+            assert epi < 1e-5                                        # E lies in the sample's null space by construction
+            over += not (cub < 1e-4 and det < 1e-4)                  # f32 storage; near-double roots are the loosest
+            worst = max(worst, cub, det)
             total += 1
             if len(ref[s]):
                 d = np.minimum(np.linalg.norm(ref[s] - e, axis=(1, 2)), np.linalg.norm(ref[s] + e, axis=(1, 2))).min()
@@ -82,6 +92,12 @@ def test_fivepoint_matches_numpy_and_constraints(device, noise, yaw):
             found_true_ref += min(np.linalg.norm(ref[s] - Et, axis=(1, 2)).min(), np.linalg.norm(ref[s] + Et, axis=(1, 2)).min()) < 1e-3
         if k and noise == 0.0:
             found_true += min(np.linalg.norm(sol - Et, axis=(1, 2)).min(), np.linalg.norm(sol + Et, axis=(1, 2)).min()) < 1e-3   # inputs are f32-rounded points
+    print(f"SOAK5 seed {seed} noise {noise:.1e} yaw {yaw} solutions {total} over_bar {over} over_bar_numpy {over_ref} worst {worst:.1e} "
+          f"matched {matched} same_count {same_count}/{S}")
+    # The committed case: every solution meets the constraint bars.  Soak seeds (POSEHOT_SOLVER_SOAK): about one minimal sample in
+    # 4 000 is ill-conditioned for Nister's elimination (which one depends on the null-space basis, so the NumPy solver's are other
+    # samples, at the same rate) and its solutions carry constraint residuals of 1e-4 .. 1e-2: a rate, not a per-solution bar.
+    assert over == 0 if seed == 0 else over <= 0.005 * total
     assert total > 2 * S                     # several real solutions per sample on average
     assert matched >= 0.98 * total           # same solution set as the NumPy solver (near-double roots may differ)
     assert same_count >= 0.95 * S
@@ -134,27 +150,32 @@ def _pnp_scene(seed, n, noise=0.0):
     return X.astype(np.float32), xy.astype(np.float32), R, t
 
 
+@pytest.mark.parametrize("seed", _SEEDS)
 @pytest.mark.parametrize("noise", [0.0, 1.0 / 3108.95])
-def test_p3p_solutions_are_solutions_and_match_numpy(device, noise):
+def test_p3p_solutions_are_solutions_and_match_numpy(device, noise, seed):
     """Every device P3P output is a rotation + translation that maps the three sample points onto their bearings
     with positive depth (the definition of a P3P solution, checked in float64 by the oracle), the solution set
     agrees with the NumPy solver (np.roots + Kabsch) and, on noise-free data, contains the true pose."""
     n, S = 400, 300
-    X, xy, R, t = _pnp_scene(11, n, noise)
+    X, xy, R, t = _pnp_scene(11 + 17 * seed, n, noise)
     nv = _t(np.array([n], np.int32), device)
-    samples = ransac.sample_minimal(5, nv, n, S, m=3)
+    samples = ransac.sample_minimal(5 + seed, nv, n, S, m=3)
     P, ns = ransac.solve_p3p(*(_t(X[:, k][None], device) for k in range(3)), _t(xy[:, 0][None], device),
                              _t(xy[:, 1][None], device), samples, want_counts=True)
     P, ns, smp = P.cpu().numpy()[0].reshape(S, 4, 3, 4), ns.cpu().numpy()[0], samples.cpu().numpy()[0]
     f_all = op.bearings(xy)
-    found = matched = total = same_count = 0
+    found = matched = total = same_count = over = n_sol = 0
+    worst = 0.0
     for s in range(S):
         Xs, fs = X[smp[s]].astype(np.float64), f_all[smp[s]]
         sols = [p for p in P[s] if np.any(p != 0)]
         assert len(sols) == ns[s] and ns[s] <= 4
         for p in sols:
             orth, det, depth, mism = op.check_solution(p[:, :3].astype(np.float64), p[:, 3].astype(np.float64), Xs, fs)
-            assert orth < 1e-5 and abs(det - 1) < 1e-5 and depth > 0 and mism < 2e-5      # f32 storage of an f64 result
+            assert orth < 1e-5 and abs(det - 1) < 1e-5 and depth > 0
+            over += not mism < 2e-5                                                       # f32 storage of an f64 result
+            worst = max(worst, mism)
+            n_sol += 1
         ref = op.solve_p3p(Xs, fs)
         same_count += len(ref) == len(sols)
         for Rr, tr in ref:
@@ -162,6 +183,10 @@ def test_p3p_solutions_are_solutions_and_match_numpy(device, noise):
             matched += any(np.abs(p[:, :3] - Rr).max() < 1e-4 and np.abs(p[:, 3] - tr).max() < 1e-4 * max(1, np.abs(tr).max())
                            for p in sols)
         found += any(np.abs(p[:, :3] - R).max() < 2e-3 and np.abs(p[:, 3] - t).max() < 2e-2 for p in sols)
+    print(f"SOAK3 seed {seed} noise {noise:.1e} solutions {n_sol} over_bar {over} worst {worst:.1e} matched {matched}/{total} "
+          f"same_count {same_count}/{S}")
+    # soak seeds: a sample with a point a few millimetres from the camera centre reproduces its bearings less tightly (a rate)
+    assert over == 0 if seed == 0 else over <= 0.005 * n_sol
     assert matched >= 0.99 * total and same_count >= 0.97 * S
     if noise == 0.0:
         assert found >= 0.99 * S     # f32 inputs: the true pose is reproduced to input precision
