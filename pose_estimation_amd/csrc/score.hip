@@ -49,6 +49,8 @@ __device__ __forceinline__ bool pnp_inlier(const float (&P)[12], float X, float 
 // matrices: few models come near the best count (17 of 4 330 within 10 %), a sixteenth of them is what it takes to hold one
 // (benchmarks/dbg/score_time.py: 64 / 128 / 256 / 576 seed models -> 0.587 / 0.546 / 0.531 / 0.541 of the exhaustive work);
 // P3P poses on 70 % inliers: a third of the models are good ones, a 64th of the block is seed enough (cfg 5: 7.28 against 7.49 ms).
+// Seed sizes that make the seed launch exactly one round of resident blocks (512 or 448 models at 64 pairs) change nothing: one
+// stream 1.796 / 1.793 against 1.801 ms per step, three streams 1.667 / 1.649 against 1.642.
 struct EssentialModel {
     static constexpr int kParams = 9, kArrays = 4, kSeedDiv = 16;
     __device__ static __forceinline__ bool test(const float (&m)[9], const float (&p)[4], float thr_sq) {
