@@ -48,6 +48,22 @@ def test_argument_errors_without_gpu():
     assert lib.ph_match_l2_ws_bytes(16, 8192, 8192, 128, 1) >= 16 * 8192 * 2 * (32 * 8 + 4)
 
 
+def test_every_entry_point_takes_empty_and_negative_sizes_without_touching_the_device():
+    """All sizes 0 with NULL pointers: a status (ok, or invalid / unsupported for a zero dimension), no launch, no dereference
+    (this process has no GPU: a launch or a HIP call would come back as PH_ERR_LAUNCH).  All sizes -1: PH_ERR_INVALID_ARG."""
+    from pose_estimation_amd import _lib
+    lib = _lib.load()
+    called = 0
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if res is not ctypes.c_int or not args:
+            continue
+        for val, allowed in ((0, (0, -1, -2)), (-1, (-1,))):
+            a = [None if t is ctypes.c_void_p else 1.0 if t is ctypes.c_float else val for t in args]
+            assert getattr(lib, name)(*a) in allowed, (name, val)
+            called += 1
+    assert called >= 2 * 40
+
+
 def test_product_never_imports_oracle():
     """The product package must not reach into oracle/ (the checker is not the thing shipped)."""
     pkg = os.path.join(ROOT, "pose_estimation_amd")
